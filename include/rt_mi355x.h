@@ -1,0 +1,216 @@
+/*
+ * rt_mi355x.h — C ABI of librt_mi355x.so, the MI355X (gfx950) path-tracing hot path.
+ *
+ * This is the drop-in boundary for the per-pixel ray-trace loop of felipeagc/sycl-ray-tracer.
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference tree). No C++ types, no torch types, no exceptions cross this boundary: plain
+ * pointers and sizes only. Every function returns RT_OK (0) or a negative rt_status;
+ * rt_last_error() returns a thread-local message for the last failure.
+ *
+ * Threading: a renderer is used from one host thread at a time (the reference is
+ * single-threaded: src/main.cpp:57-70). Different renderers may be used from different threads.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument (null pointer, out-of-range index, zero size) */
+    RT_ERR_NO_DEVICE = -2,   /* no usable gfx950 device / HIP runtime not functional      */
+    RT_ERR_HIP = -3,         /* a HIP call failed; message carries hipGetErrorString      */
+    RT_ERR_OOM = -4,         /* host or device allocation failed                          */
+    RT_ERR_UNSUPPORTED = -5  /* valid request this build does not implement               */
+} rt_status;
+
+/* ---- texture array constants: src/image_manager.hpp:12-14 --------------------------------- */
+#define RT_TEX_SIZE 512u      /* IMAGE_SIZE = {512,512}            */
+#define RT_TEX_CHANNELS 4u    /* IMAGE_CHANNELS                     */
+#define RT_TEX_MAX_LAYERS 128u /* MAX_IMAGES                        */
+
+/* ---- Camera: the by-value POD the kernels consume, == raytracer::Camera (src/camera.hpp:65-72)
+ * center / pixel00_loc / pixel_delta_u / pixel_delta_v / img_size. */
+typedef struct rt_camera {
+    float center[3];
+    float pixel00[3];
+    float delta_u[3];
+    float delta_v[3];
+    int32_t width;
+    int32_t height;
+} rt_camera;
+
+/* Host-side camera constructor == Camera::Camera(img_size, cam_center, cam_dir, focal_length)
+ * (src/camera.hpp:74-106). Pure host arithmetic; needs no GPU. */
+int rt_camera_init(rt_camera* out, int32_t width, int32_t height, const float center[3],
+                   const float dir[3], float focal_length);
+
+/* ---- Materials: == raytracer::Material tagged union (src/material.hpp:56-61,163-238) ------- */
+enum { RT_MAT_NONE = 0, RT_MAT_DIFFUSE = 1, RT_MAT_METALLIC = 2, RT_MAT_DIELECTRIC = 3 };
+/* == TextureType (src/material.hpp:13-16) */
+enum { RT_TEX_COLOR = 0, RT_TEX_IMAGE = 1 };
+
+typedef struct rt_material {
+    uint32_t type;      /* RT_MAT_*                                                        */
+    uint32_t tex_kind;  /* RT_TEX_*: albedo is `color` or layer `tex_layer` of the array   */
+    float color[3];     /* Texture::color  (baseColorFactor.rgb)                           */
+    uint32_t tex_layer; /* ImageRef::index (src/image_manager.hpp:26-28)                   */
+    float emissive[3];  /* MaterialDiffuse/Metallic::emissive; ignored for dielectric      */
+    float roughness;    /* MaterialMetallic::roughness                                     */
+    float ior;          /* MaterialDielectric::ior                                         */
+} rt_material;          /* 44 bytes */
+
+/* ---- Instance: one Embree instance geometry + its GeometryData (src/scene.hpp:17-24,
+ * filled at src/scene.cpp:487-505). `transform` is the 4x4 column-major global matrix handed
+ * to rtcSetGeometryTransform; `normal_mat` is GeometryData::obj_to_world =
+ * transpose(inverse(mat3(global))) as a column-major 3x3. The index of an instance in the
+ * array is Embree's instID[0] (attach order, src/scene.cpp:101-106). */
+typedef struct rt_instance {
+    float transform[16];
+    float normal_mat[9];
+    uint32_t material; /* index into rt_scene_desc::materials */
+} rt_instance;         /* 104 bytes */
+
+/* ---- Scene description: flat, caller-owned host arrays, copied during rt_scene_create.
+ * Replaces what trace_ray reaches through RTCScene + GeometryData (src/trace_ray.hpp:18-45):
+ *   positions/normals/uvs : object-space vertex attributes (GeometryData::vertex/normal/uv_buffer)
+ *   indices               : 3 vertex indices per triangle (GeometryData::index_buffer), already
+ *                           offset into the shared vertex arrays
+ *   tri_instance          : instance (instID) of each triangle; triangles of one instance are
+ *                           contiguous and in primID order
+ *   textures              : n_layers x 512 x 512 x RGBA8, row 0 first (image_manager.hpp:76-100)
+ *   sky                   : Scene::sky_color (src/scene.hpp:76) */
+typedef struct rt_scene_desc {
+    uint32_t n_vertices;
+    const float* positions;       /* 3 * n_vertices */
+    const float* normals;         /* 3 * n_vertices */
+    const float* uvs;             /* 2 * n_vertices */
+    uint32_t n_triangles;
+    const uint32_t* indices;      /* 3 * n_triangles */
+    const uint32_t* tri_instance; /* n_triangles */
+    uint32_t n_instances;
+    const rt_instance* instances;
+    uint32_t n_materials;
+    const rt_material* materials;
+    uint32_t n_layers;
+    const uint8_t* textures;      /* n_layers * 512*512*4, may be NULL iff n_layers == 0 */
+    float sky[3];
+} rt_scene_desc;
+
+typedef struct rt_scene rt_scene;       /* opaque: device-resident flattened triangles + BVH */
+typedef struct rt_renderer rt_renderer; /* opaque: ray queues, RNG states, accumulators      */
+
+/* BVH builder selection for rt_scene_create (the image is independent of the choice). */
+enum { RT_BVH_DEFAULT = 0, RT_BVH_LBVH = 1, RT_BVH_SAH = 2 };
+
+/* Builds the world-space triangle set and the BVH, uploads everything to HIP device `device`.
+ * Replaces Scene's Embree side: rtcNewScene/rtcAttachGeometry/rtcCommitScene
+ * (src/scene.cpp:101-107,406-439,487-507). device < 0 builds a host-only scene (no HIP call):
+ * usable with rt_scene_info / rt_scene_check_bvh only. */
+int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+typedef struct rt_scene_info_t {
+    uint32_t n_triangles;
+    uint32_t n_nodes;
+    uint32_t max_depth;     /* deepest leaf */
+    uint32_t max_leaf_tris;
+    float bounds_lo[3];
+    float bounds_hi[3];
+    double sah_cost;        /* surface-area-heuristic cost of the tree (diagnostic) */
+    uint64_t device_bytes;  /* bytes resident in HBM for this scene */
+} rt_scene_info_t;
+int rt_scene_info(const rt_scene* scene, rt_scene_info_t* out);
+
+/* Host-side structural check of the built BVH: every triangle in exactly one leaf, every child
+ * box inside its parent's, every triangle inside its leaf box. Returns RT_OK or RT_ERR_INVALID
+ * (message names the first violation). Needs no GPU. */
+int rt_scene_check_bvh(const rt_scene* scene);
+
+/* Closest-hit query for a batch of rays: the replacement for rtcIntersect1 at
+ * src/trace_ray.hpp:18-27 (tnear = 1e-4, tfar = +inf, no culling, no masks).
+ * org/dir: 3*n floats (host). Outputs (host, n each): t (+inf on miss), u, v and
+ * tri = global triangle index in rt_scene_desc order (0xFFFFFFFF on miss). */
+int rt_intersect_batch(rt_scene* scene, uint32_t n, const float* org, const float* dir, float* t,
+                       float* u, float* v, uint32_t* tri);
+
+/* ---- Renderers: == IRenderer implementations (src/render.hpp:11-18) ------------------------ */
+enum {
+    RT_RENDERER_MEGAKERNEL = 0, /* MegakernelRenderer (src/render_megakernel.hpp:13-19) */
+    RT_RENDERER_WAVEFRONT = 1   /* WavefrontRenderer  (src/render_wavefront.hpp:55-61)  */
+};
+/* Per-pixel xorshift seed:
+ *   RT_SEED_WAVEFRONT : x + y*W                        (src/render_wavefront.cpp:69-73)
+ *   RT_SEED_MEGAKERNEL: x*H8 + y, H8 = 8*ceil(H/8)     (src/render_megakernel.cpp:90-93,144-146)
+ *   RT_SEED_DEFAULT   : the renderer kind's own rule */
+enum { RT_SEED_DEFAULT = 0, RT_SEED_WAVEFRONT = 1, RT_SEED_MEGAKERNEL = 2 };
+
+/* == the renderer constructors (App&, img_size, image&, max_depth, sample_count). The output
+ * image is passed to rt_render_frame instead of being captured by reference. */
+int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
+                       uint32_t max_depth, uint32_t sample_count, uint32_t seed_mode,
+                       rt_renderer** out);
+void rt_renderer_destroy(rt_renderer* r);
+
+/* Multi-GPU tile split (no reference counterpart: the reference is single-device). The frame is
+ * cut into horizontal strips of `strip_rows` rows; strip k belongs to rank k % world. A renderer
+ * renders only its own strips, packed top to bottom into a compact buffer of
+ * rt_renderer_local_rows() rows. RNG seeds use GLOBAL pixel coordinates, so the union of the
+ * tiles is bit-identical to a single-GPU frame. Default: rank 0 of world 1. */
+int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t strip_rows);
+int32_t rt_renderer_local_rows(const rt_renderer* r);
+/* Global row index of local row `local_row` (for de-interleaving a gathered frame). */
+int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row);
+
+typedef struct rt_stats {
+    uint64_t rays;       /* trace_ray calls (src/render_megakernel.cpp:32, render_wavefront.cpp:407) */
+    double seconds;      /* host wall clock, first launch -> last kernel complete                  */
+    double device_ms;    /* same region measured with hipEvents on the render stream               */
+    double hot_kernel_ms;/* summed duration of the dominant kernel's launches (hipEvents), or 0    */
+    uint32_t hot_kernel_launches;
+    uint32_t launches;   /* kernel launches issued for the frame                                   */
+} rt_stats;
+
+/* == IRenderer::render_frame(camera, scene) (src/render_megakernel.cpp:75-187,
+ * src/render_wavefront.cpp:396-431). Renders this renderer's tile and copies it to host:
+ *   rgba_f32: local_rows*W*4 floats, the pre-quantisation framebuffer (sqrt(mean rgb), alpha 1)
+ *   rgba_u8 : local_rows*W*4 bytes, what the reference's RGBA-unorm8 image holds
+ * Either may be NULL. Unlike the reference it prints nothing and writes no file: the caller
+ * (host adapter / CLI) prints the three stat lines and writes out.png. */
+int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8,
+                    rt_stats* stats);
+
+/* Same, but the outputs are DEVICE pointers on the renderer's device (e.g. a tensor's data_ptr)
+ * and `stream` is a hipStream_t (NULL = the renderer's own stream). Returns after the frame has
+ * completed on the device (stats need the ray counter). */
+int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32,
+                           void* d_rgba_u8, void* stream, rt_stats* stats);
+
+/* ---- Device unit probes (parity tests of the building blocks; tiny launches) --------------- */
+/* XorShift32State::operator() (src/xorshift.hpp:11-20) run on the device: n draws from `seed`. */
+int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out);
+/* float -> half -> float round trip as RayData stores dir/att/rad (src/camera.hpp:18-43). */
+int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out,
+                            uint16_t* bits_out);
+/* Material::scatter (src/material.hpp:211-224) on the device for n independent inputs:
+ * dir/normal: 3n, uv: 2n, seed: n. Outputs ok (n, 0/1), out_dir 3n, out_att 3n, seed_out n. */
+int rt_probe_scatter(rt_scene* scene, uint32_t material, uint32_t n, const float* dir,
+                     const float* normal, const float* uv, const uint32_t* seed, uint8_t* ok,
+                     float* out_dir, float* out_att, uint32_t* seed_out);
+
+const char* rt_last_error(void);
+int rt_abi_version(void);
+/* Number of HIP devices visible, or a negative rt_status. */
+int rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */
