@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — the headline benchmark: Mrays/s and ms/frame on the Sponza-like atrium, 1920x1080, 64 spp,
+max depth 10 (BASELINE.json configs[3]), on N GPUs of one node.
+
+A "step" is one full frame. One process per GPU (torch.distributed / RCCL): rank r renders the 8-row strips
+k with k % N == r of the SAME frame (strong scaling: total work is fixed), then the per-rank strip buffers
+are gathered to rank 0 over xGMI and de-interleaved there. Scene, BVH and ray queues are resident in HBM
+before the timed region; the frame stays on the device (no PCIe traffic inside the timed region).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel (k_wf_shoot) algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
+  cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WAVEFRONT_BYTES_PER_RAY = 76   # 34 B state read + 8 B RNG r/w + 34 B state write
+MEGAKERNEL_BYTES_PER_PIXEL = 20  # one fp32 RGBA store + one RGBA8 store per pixel per frame
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--renderer", choices=["wavefront", "megakernel"], default=os.environ.get("RT_BENCH_RENDERER", "wavefront"))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--detail", type=int, default=4, help="atrium tessellation (4 = ~281k triangles)")
+    ap.add_argument("--bvh", choices=["sah", "lbvh"], default="sah")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=1, help="samples per pixel of the bounded CPU-oracle sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from rtamd import abi, scenes
+    from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, strip = args.width, args.height, 8
+    sd = scenes.atrium_scene(args.detail)
+    scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+    cam = Camera.for_scene(sd, (W, H))
+    cls = WavefrontRenderer if args.renderer == "wavefront" else MegakernelRenderer
+    r = cls(scene, (W, H), args.depth, args.spp)
+    r.set_tile(rank, world, strip)
+    r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the render stream
+    rows = r.local_rows
+    max_rows = max(sum(1 for y in range(H) if (y // strip) % world == k) for k in range(world))
+    local = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=dev)  # padded to equal size for gather
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+    gathered = [torch.zeros_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
+    row_index = None
+    if rank == 0:
+        row_index = [torch.tensor([y for y in range(H) if (y // strip) % world == k], dtype=torch.long, device=dev)
+                     for k in range(world)]
+
+    def step():
+        fr = r.render_frame_device(cam, d_f32=local.data_ptr())
+        if world > 1:
+            dist.gather(local, gathered, dst=0)  # RCCL gather of the per-GPU strip buffers
+            if rank == 0:
+                for k in range(world):
+                    frame.index_copy_(0, row_index[k], gathered[k][: row_index[k].numel()])
+        else:
+            frame.index_copy_(0, row_index[0], local[:rows])
+        return fr
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    hot_ms, hot_launches, dev_ms = 0.0, 0, 0.0
+    for _ in range(args.steps):
+        fr = step()
+        rays += fr.rays
+        hot_ms += fr.hot_kernel_ms
+        hot_launches += fr.hot_kernel_launches
+        dev_ms += fr.device_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(rays), hot_ms, float(hot_launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        rays_all = float(sm[1])
+    else:
+        rays_all = float(rays)
+
+    if rank == 0:
+        mrays = rays_all / elapsed / 1e6
+        # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch time
+        if args.renderer == "wavefront":
+            kernel, bytes_per_launch = "k_wf_shoot", WAVEFRONT_BYTES_PER_RAY * rays / max(hot_launches, 1)
+        else:
+            kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
+        mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
+        achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}",
+                       "renderer": args.renderer, "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}",
+                       "rays_per_frame": int(rays_all / args.steps)},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "launches": hot_launches, "mean_launch_ms": round(mean_launch_s * 1e3, 5),
+                         "bytes_per_launch": round(bytes_per_launch, 1),
+                         "note": "incoherent BVH traversal is latency/divergence-bound; HBM fraction is small by construction (DESIGN.md §6)"},
+            "device_ms_per_step": round(dev_ms / args.steps, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, args.renderer)
+        print(json.dumps(out), flush=True)
+    r.close()
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(sd, W, H, depth, spp, renderer):
+    """The CPU oracle (oracle/oracle_rt.cpp: a port of the reference's algorithm, std::thread over rows) on the
+    same scene/camera/seeds at the same resolution but `spp` samples instead of 64 (rays/s does not depend on
+    spp: benchmark_avg.csv:12,2,16,18 of the reference)."""
+    from oracle import oracle as O
+    from rtamd import abi
+    osc = O.OracleScene(sd)
+    cam = O.camera(W, H, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    kind = abi.RT_RENDERER_WAVEFRONT if renderer == "wavefront" else abi.RT_RENDERER_MEGAKERNEL
+    cores = O.hardware_threads()
+    t0 = time.perf_counter()
+    _, _, rays = osc.render(cam, kind, depth, spp, use_bvh=True, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"same scene and camera, {W}x{H}, {spp} spp (of 64), depth {depth}: {rays} rays in {dt:.1f} s",
+            "note": "CPU restatement of the reference (oracle/), not the reference's SYCL build"}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -195,18 +195,22 @@ constexpr float T_NEAR = 0.0001f; // RayData::to_embree tnear, src/camera.hpp:50
 // R5: Moller-Trumbore; barycentrics follow Embree's convention P = (1-u-v) v0 + u v1 + v v2
 // (usage at src/trace_ray.hpp:48-54).
 inline void mt_hit(const Tri& tr, uint32_t idx, V3 o, V3 d, Hit& best) {
+    // Edge tests are made on the un-divided numerators (sign-corrected by det), so the one
+    // correctly-rounded division is spent only on triangles that pass them.
     V3 p = cross(d, tr.e2);
     float det = dot(tr.e1, p);
     if (!(det != 0.0f)) return; // parallel (or NaN)
-    float inv = 1.0f / det;
     V3 tv = o - tr.v0;
-    float u = dot(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return;
     V3 q = cross(tv, tr.e1);
-    float v = dot(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return;
+    float sgn = det < 0.0f ? -1.0f : 1.0f;
+    float un = dot(tv, p) * sgn;
+    float vn = dot(d, q) * sgn;
+    if (!(un >= 0.0f && vn >= 0.0f && un + vn <= fabsf(det))) return;
+    float inv = 1.0f / det;
     float t = dot(tr.e2, q) * inv;
     if (!(t > T_NEAR)) return;
+    float u = dot(tv, p) * inv;
+    float v = dot(d, q) * inv;
     if (t < best.t || (t == best.t && idx < best.tri)) {
         best.t = t;
         best.u = u;

@@ -1,0 +1,313 @@
+// rt_device.h — gfx950 device functions of the ray-trace hot path.
+//
+// Each function names the reference code it stands for (file:line under the reference tree).
+// Arithmetic contract: single IEEE-754 binary32 operations evaluated as written,
+// left to right, no FMA contraction (this TU is compiled with -ffp-contract=off), correctly
+// rounded division and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt), half storage with
+// round-to-nearest-even. The ONLY place that uses fused/approximate arithmetic is the BVH box
+// test, which merely culls (boxes are padded) and cannot change a result.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_types.h"
+
+namespace rt {
+
+#define RT_DEV __device__ __forceinline__
+
+struct f3 {
+    float x, y, z;
+};
+RT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// glm::normalize / sycl::normalize: v * (1 / sqrt(dot(v,v)))
+RT_DEV f3 normalize3(f3 a) {
+    float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+RT_DEV float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+
+// sycl::half storage of dir / attenuation / radiance (src/camera.hpp:18-43)
+RT_DEV uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f; // v_cvt_f16_f32, round-to-nearest-even
+    return __builtin_bit_cast(uint16_t, h);
+}
+RT_DEV float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// ---- XorShift32State (src/xorshift.hpp:8-49) -------------------------------------------------------
+RT_DEV float rng_next(uint32_t& a) { // operator()(): :11-20
+    uint32_t x = a;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    a = x;
+    return (float)x * (1.0f / 4294967296.0f);
+}
+RT_DEV float rng_range(uint32_t& a, float mn, float mx) { return mn + (mx - mn) * rng_next(a); } // :22-24
+RT_DEV f3 rng_unit_vector(uint32_t& a) { // vec(-1,1) then normalize: :30-40, draws in x,y,z order
+    float x = rng_range(a, -1.0f, 1.0f);
+    float y = rng_range(a, -1.0f, 1.0f);
+    float z = rng_range(a, -1.0f, 1.0f);
+    return normalize3(mk3(x, y, z));
+}
+
+// per-pixel seed: std::hash<size_t> is the identity (src/render_wavefront.cpp:69-73,
+// src/render_megakernel.cpp:90-93,144-146)
+RT_DEV uint32_t pixel_seed(int x, int y, int w, int h, uint32_t seed_mode) {
+    if (seed_mode == RT_SEED_MEGAKERNEL) {
+        uint32_t h8 = (uint32_t)((h + 7) / 8) * 8u;
+        return (uint32_t)x * h8 + (uint32_t)y;
+    }
+    return (uint32_t)x + (uint32_t)y * (uint32_t)w;
+}
+
+// local (tile) row -> global image row
+RT_DEV int tile_global_row(const TileDev& t, int local_row) {
+    uint32_t strip = (uint32_t)local_row / t.strip_rows;
+    uint32_t within = (uint32_t)local_row % t.strip_rows;
+    return (int)((strip * t.world + t.rank) * t.strip_rows + within);
+}
+
+// ---- ray state: RayData (src/camera.hpp:12-44) -----------------------------------------------------
+struct RayState {
+    f3 org;
+    uint16_t dir[3], att[3], rad[3];
+};
+
+// Camera::get_ray + pixel_sample_square (src/camera.hpp:109-131) and the RayData ctor (:30-44)
+RT_DEV RayState camera_ray(const CameraDev& c, int x, int y, uint32_t& rng) {
+    f3 p00 = mk3(c.pixel00[0], c.pixel00[1], c.pixel00[2]);
+    f3 du = mk3(c.du[0], c.du[1], c.du[2]);
+    f3 dv = mk3(c.dv[0], c.dv[1], c.dv[2]);
+    f3 center = mk3(c.center[0], c.center[1], c.center[2]);
+    f3 pixel_center = (p00 + ((float)x * du)) + ((float)y * dv);
+    float px = -0.5f + rng_next(rng);
+    float py = -0.5f + rng_next(rng);
+    f3 jitter = (px * du) + (py * dv);
+    f3 pixel_sample = pixel_center + jitter;
+    f3 d = pixel_sample - center;
+    RayState r;
+    r.org = center;
+    r.dir[0] = f2h(d.x), r.dir[1] = f2h(d.y), r.dir[2] = f2h(d.z);
+    r.att[0] = r.att[1] = r.att[2] = 0x3C00; // half(1.0)
+    r.rad[0] = r.rad[1] = r.rad[2] = 0;      // half(0.0)
+    return r;
+}
+
+// ---- closest hit: replaces rtcIntersect1 (src/trace_ray.hpp:18-27) ---------------------------------
+struct Hit {
+    float t, u, v;
+    uint32_t tri; // global triangle index, kNoTri on a miss
+};
+
+// Moller-Trumbore on the precomputed (v0, e1, e2); barycentrics in Embree's convention
+// P = (1-u-v) v0 + u v1 + v v2. Edge tests on the sign-corrected numerators; one division per
+// accepted candidate. Minimum t wins, equal t -> lowest global index (order independent).
+RT_DEV void tri_test(const TriRec* __restrict__ tr, f3 o, f3 d, Hit& best) {
+    const float4* p4 = reinterpret_cast<const float4*>(tr);
+    const float4 a = p4[0], b = p4[1], c = p4[2];
+    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+    const uint32_t gidx = __float_as_uint(c.y);
+    const f3 p = cross3(d, e2);
+    const float det = dot3(e1, p);
+    if (!(det != 0.0f)) return;
+    const f3 tv = o - v0;
+    const f3 q = cross3(tv, e1);
+    const float sgn = det < 0.0f ? -1.0f : 1.0f;
+    const float un0 = dot3(tv, p), vn0 = dot3(d, q);
+    const float un = un0 * sgn, vn = vn0 * sgn;
+    if (!(un >= 0.0f && vn >= 0.0f && un + vn <= __builtin_fabsf(det))) return;
+    const float inv = 1.0f / det;
+    const float t = dot3(e2, q) * inv;
+    if (!(t > kTNear)) return;
+    if (t < best.t || (t == best.t && gidx < best.tri)) {
+        best.t = t;
+        best.u = un0 * inv;
+        best.v = vn0 * inv;
+        best.tri = gidx;
+    }
+}
+
+// BVH2 traversal, one ray per lane, explicit stack. The box test is a padded-box cull: it uses
+// fma and an approximate reciprocal on purpose (never visible in results).
+RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d) {
+    Hit best;
+    best.t = __builtin_huge_valf();
+    best.u = best.v = 0.0f;
+    best.tri = kNoTri;
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    int32_t stack[kStackSize];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            const float4 bx = np[0], by = np[1], bz = np[2];
+            const int2 ch = *reinterpret_cast<const int2*>(np + 3);
+            // child 0
+            float x0 = __builtin_fmaf(bx.x, ix, ox), x1 = __builtin_fmaf(bx.y, ix, ox);
+            float y0 = __builtin_fmaf(by.x, iy, oy), y1 = __builtin_fmaf(by.y, iy, oy);
+            float z0 = __builtin_fmaf(bz.x, iz, oz), z1 = __builtin_fmaf(bz.y, iz, oz);
+            float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
+                                        __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+            float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
+                                        __builtin_fminf(__builtin_fmaxf(z0, z1), best.t));
+            // child 1
+            x0 = __builtin_fmaf(bx.z, ix, ox), x1 = __builtin_fmaf(bx.w, ix, ox);
+            y0 = __builtin_fmaf(by.z, iy, oy), y1 = __builtin_fmaf(by.w, iy, oy);
+            z0 = __builtin_fmaf(bz.z, iz, oz), z1 = __builtin_fmaf(bz.w, iz, oz);
+            float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
+                                        __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+            float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
+                                        __builtin_fminf(__builtin_fmaxf(z0, z1), best.t));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                stack[sp++] = swap ? ch.x : ch.y; // far child waits
+                cur = swap ? ch.y : ch.x;
+                continue;
+            }
+            if (h0) { cur = ch.x; continue; }
+            if (h1) { cur = ch.y; continue; }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+            const TriRec* tr = S.tris + first;
+            for (uint32_t k = 0; k < count; ++k) tri_test(tr + k, o, d, best);
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
+// ---- materials (src/material.hpp, src/util.hpp:82-125) ----------------------------------------------
+RT_DEV bool near_zero3(f3 e) { // src/util.hpp:103-107
+    const float s = 1e-8f;
+    return (__builtin_fabsf(e.x) < s) && (__builtin_fabsf(e.y) < s) && (__builtin_fabsf(e.z) < s);
+}
+RT_DEV float length_squared3(f3 v) { // src/util.hpp:109-112: length(v) * length(v)
+    float l = __builtin_sqrtf(dot3(v, v));
+    return l * l;
+}
+RT_DEV f3 reflect3(f3 v, f3 n) { return v - (2.0f * dot3(v, n)) * n; } // src/util.hpp:114-116
+RT_DEV f3 refract3(f3 uv, f3 n, float etai_over_etat) {                // src/util.hpp:118-125
+    float cos_theta = __builtin_fminf(dot3(-uv, n), 1.0f);
+    f3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    f3 r_out_parallel = (-__builtin_sqrtf(__builtin_fabsf(1.0f - length_squared3(r_out_perp)))) * n;
+    return r_out_perp + r_out_parallel;
+}
+// MaterialDielectric::reflectance (src/material.hpp:120-125); pow(x,5) = ((x*x)*(x*x))*x
+RT_DEV float schlick(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x5 = (x2 * x2) * x;
+    return r0 + (1.0f - r0) * x5;
+}
+// Texture::sample (src/material.hpp:45-53): constant colour, or nearest / repeat / normalised
+// fetch from layer tex_layer of the 512x512 RGBA8 array (sampler: src/render_wavefront.cpp:193-197)
+RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
+    if (m.tex_kind == RT_TEX_COLOR) return mk3(m.color[0], m.color[1], m.color[2]);
+    float fu = u - __builtin_floorf(u);
+    float fv = v - __builtin_floorf(v);
+    int iu = (int)__builtin_floorf(fu * 512.0f);
+    int iv = (int)__builtin_floorf(fv * 512.0f);
+    iu = iu < 0 ? 0 : (iu > 511 ? 511 : iu);
+    iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
+    const uint32_t texel = *reinterpret_cast<const uint32_t*>(
+        S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u);
+    return mk3((float)(texel & 0xffu) / 255.0f, (float)((texel >> 8) & 0xffu) / 255.0f,
+               (float)((texel >> 16) & 0xffu) / 255.0f);
+}
+
+// Material::scatter (src/material.hpp:211-224) with the three material bodies (:72-86, :98-110,
+// :127-156). Returns false when the path is absorbed.
+RT_DEV bool scatter(const SceneDev& S, const MatRec& m, uint32_t& rng, f3 dir, f3 normal, float u, float v,
+                    f3& out_dir, f3& out_att) {
+    if (m.type == RT_MAT_DIFFUSE) {
+        out_dir = normal + rng_unit_vector(rng);
+        if (near_zero3(dir)) out_dir = normal; // tests the incoming direction, as the reference does
+        out_att = albedo(S, m, u, v);
+        return true;
+    }
+    if (m.type == RT_MAT_METALLIC) {
+        f3 reflected = reflect3(dir, normal);
+        out_dir = reflected + m.roughness * rng_unit_vector(rng);
+        out_att = albedo(S, m, u, v);
+        return dot3(out_dir, normal) > 0.0f;
+    }
+    if (m.type == RT_MAT_DIELECTRIC) {
+        out_att = mk3(1.0f, 1.0f, 1.0f);
+        bool front_face = dot3(dir, normal) < 0.0f;
+        f3 n = front_face ? normal : -normal;
+        float ratio = front_face ? (1.0f / m.ior) : m.ior;
+        f3 unit_direction = normalize3(dir);
+        float cos_theta = __builtin_fminf(dot3(-unit_direction, n), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        bool reflect_it = ratio * sin_theta > 1.0f;
+        if (!reflect_it) reflect_it = schlick(cos_theta, ratio) > rng_range(rng, 0.0f, 1.0f); // draw only if refractable
+        out_dir = reflect_it ? reflect3(unit_direction, n) : refract3(unit_direction, n, ratio);
+        return true;
+    }
+    out_dir = mk3(0.0f, 0.0f, 0.0f);
+    out_att = mk3(0.0f, 0.0f, 0.0f);
+    return false; // eNone
+}
+
+// ---- trace_ray (src/trace_ray.hpp:11-82): one bounce ------------------------------------------------
+// Returns true and sets `result` when the path ends (miss -> att*(sky+rad); absorbed -> att*rad);
+// otherwise updates org/dir/att and returns false. `dir` is the unnormalised float direction.
+RT_DEV bool trace_ray(const SceneDev& S, uint32_t& rng, f3& org, f3& dir, f3& att, f3& rad, f3& result) {
+    const Hit h = intersect(S, org, dir);
+    if (h.tri == kNoTri) {
+        result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+        return true;
+    }
+    const float4* sp = reinterpret_cast<const float4*>(S.shade + h.tri);
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+    const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+    const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
+    const uint32_t inst_id = __float_as_uint(s3.w);
+    const InstRec& inst = S.inst[inst_id];
+    const MatRec& mat = S.mats[inst.material];
+    const float bx = h.u, by = h.v;
+    const float w = (1.0f - bx) - by;
+    const float tu = (w * uv0x + bx * uv1x) + by * uv2x;
+    const float tv = (w * uv0y + bx * uv1y) + by * uv2y;
+    const f3 vn = normalize3((w * n0 + bx * n1) + by * n2);
+    const float* nm = inst.normal_mat;
+    const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
+                     (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
+    const f3 normal = normalize3(g);
+    const f3 d = normalize3(dir);
+    const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237
+    rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
+    f3 sdir, satt;
+    if (scatter(S, mat, rng, d, normal, tu, tv, sdir, satt)) {
+        org = mk3(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
+        dir = sdir;
+        att = att * satt;
+        return false;
+    }
+    result = att * rad;
+    return true;
+}
+
+// unorm8 image write (saturate, round to nearest even) followed by write_image's (uint8)(c*255)
+// read-back (src/util.hpp:17-22)
+RT_DEV uint8_t to_unorm8(float c) { return (uint8_t)__builtin_rintf(clamp01(c) * 255.0f); }
+
+} // namespace rt

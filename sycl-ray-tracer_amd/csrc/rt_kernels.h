@@ -1,0 +1,245 @@
+// rt_kernels.h — the gfx950 kernels of the two renderers (wave64; block sizes are multiples of 64).
+//
+//   k_megakernel   == K1, MegakernelRenderer's single kernel (src/render_megakernel.cpp:116-168)
+//   k_wf_init      == K2, WavefrontRenderer ctor init        (src/render_wavefront.cpp:62-74)
+//   k_wf_generate  == K3, generate_camera_rays               (src/render_wavefront.cpp:106-124)
+//   k_wf_shoot     == K4, shoot_rays + K5 merge_samples fused (src/render_wavefront.cpp:222-312,340-354)
+//   k_wf_resolve   == K6 convert_image_to_srgb + K7 write_image (:377-390, src/util.hpp:16-23)
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+// SoA ray queue: 34 bytes per ray in four coalesced planes (the reference's Buffers pads the same
+// state to 44 bytes: src/render_wavefront.hpp:10-38).
+//   org_id : (org.x, org.y, org.z, bits(pixel id))           16 B
+//   a      : halves (dir.x, dir.y, dir.z, att.r)              8 B
+//   b      : halves (att.g, att.b, rad.r, rad.g)              8 B
+//   c      : half   (rad.b)                                   2 B
+struct QueueDev {
+    float4* org_id;
+    uint2* a;
+    uint2* b;
+    uint16_t* c;
+};
+
+RT_DEV void queue_store(const QueueDev& q, uint32_t slot, uint32_t id, const RayState& r) {
+    q.org_id[slot] = make_float4(r.org.x, r.org.y, r.org.z, __uint_as_float(id));
+    q.a[slot] = make_uint2((uint32_t)r.dir[0] | ((uint32_t)r.dir[1] << 16), (uint32_t)r.dir[2] | ((uint32_t)r.att[0] << 16));
+    q.b[slot] = make_uint2((uint32_t)r.att[1] | ((uint32_t)r.att[2] << 16), (uint32_t)r.rad[0] | ((uint32_t)r.rad[1] << 16));
+    q.c[slot] = r.rad[2];
+}
+RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
+    const float4 o = q.org_id[slot];
+    const uint2 a = q.a[slot], b = q.b[slot];
+    const uint16_t c = q.c[slot];
+    r.org = mk3(o.x, o.y, o.z);
+    r.dir[0] = (uint16_t)a.x, r.dir[1] = (uint16_t)(a.x >> 16), r.dir[2] = (uint16_t)a.y;
+    r.att[0] = (uint16_t)(a.y >> 16), r.att[1] = (uint16_t)b.x, r.att[2] = (uint16_t)(b.x >> 16);
+    r.rad[0] = (uint16_t)b.y, r.rad[1] = (uint16_t)(b.y >> 16), r.rad[2] = c;
+    return __float_as_uint(o.w);
+}
+
+// one bounce on a RayState: unpack halves -> trace_ray -> repack (the body of render_pixel's loop,
+// src/render_megakernel.cpp:34-55, and of shoot_rays, src/render_wavefront.cpp:245-291)
+RT_DEV bool bounce(const SceneDev& S, uint32_t& rng, RayState& r, f3& result) {
+    f3 org = r.org;
+    f3 dir = mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2]));
+    f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
+    f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
+    const bool done = trace_ray(S, rng, org, dir, att, rad, result);
+    r.org = org;
+    r.dir[0] = f2h(dir.x), r.dir[1] = f2h(dir.y), r.dir[2] = f2h(dir.z);
+    r.att[0] = f2h(att.x), r.att[1] = f2h(att.y), r.att[2] = f2h(att.z);
+    r.rad[0] = f2h(rad.x), r.rad[1] = f2h(rad.y), r.rad[2] = f2h(rad.z);
+    return done;
+}
+
+RT_DEV uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v; // valid in lane 0
+}
+
+// ---- K1: megakernel ---------------------------------------------------------------------------------
+// One lane per pixel; a 64-thread block is one wave covering an 8x8 pixel tile. The sample and
+// depth loops of render_pixel are flattened into ONE loop so a lane whose path ended starts its
+// next sample at once instead of idling until the wave's longest path finishes.
+__global__ void __launch_bounds__(64) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+                                                    uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
+                                                    uint8_t* __restrict__ out_u8,
+                                                    unsigned long long* __restrict__ ray_counter) {
+    const int tiles_x = (cam.width + 7) >> 3;
+    const int tx = (int)(blockIdx.x % (uint32_t)tiles_x), ty = (int)(blockIdx.x / (uint32_t)tiles_x);
+    const int lane = (int)threadIdx.x;
+    const int x = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3); // local row
+    const int gy = tile_global_row(tile, ly);
+    const bool active = x < cam.width && ly < tile.local_rows && gy < cam.height;
+    uint32_t rays = 0;
+    if (active) {
+        uint32_t rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
+        f3 color = mk3(0.0f, 0.0f, 0.0f);
+        if (max_depth == 0) {
+            for (uint32_t s = 0; s < spp; ++s) (void)camera_ray(cam, x, gy, rng);
+        } else {
+            uint32_t s = 0, depth = 0;
+            RayState r = camera_ray(cam, x, gy, rng);
+            while (s < spp) {
+                f3 res;
+                rays++;
+                const bool done = bounce(S, rng, r, res);
+                depth++;
+                if (done || depth == max_depth) {
+                    if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
+                    s++;
+                    depth = 0;
+                    if (s < spp) r = camera_ray(cam, x, gy, rng);
+                }
+            }
+        }
+        const float n = (float)spp;
+        const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
+        const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
+        if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+        if (out_u8)
+            reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+                                                     ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+    }
+    const uint32_t total = wave_sum_u32(rays);
+    if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
+}
+
+// ---- K2: seed RNG states, zero the accumulator --------------------------------------------------------
+__global__ void __launch_bounds__(256) k_wf_init(CameraDev cam, TileDev tile, uint32_t seed_mode, uint32_t n_local,
+                                                  uint32_t* __restrict__ rng, float4* __restrict__ accum) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_local) return;
+    const int x = (int)(i % (uint32_t)cam.width), ly = (int)(i / (uint32_t)cam.width);
+    const int gy = tile_global_row(tile, ly);
+    rng[i] = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
+    accum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- K3: camera rays for every pixel of the tile into queue slot = local pixel index -----------------
+__global__ void __launch_bounds__(256) k_wf_generate(CameraDev cam, TileDev tile, uint32_t n_local,
+                                                      uint32_t* __restrict__ rng, QueueDev q,
+                                                      uint32_t* __restrict__ count_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) *count_out = n_local; // "*ray_buffer_length = img_size.size()" (src/render_wavefront.cpp:104)
+    if (i >= n_local) return;
+    const int x = (int)(i % (uint32_t)cam.width), ly = (int)(i / (uint32_t)cam.width);
+    const int gy = tile_global_row(tile, ly);
+    uint32_t st = rng[i];
+    const RayState r = gy < cam.height ? camera_ray(cam, x, gy, st) : RayState{};
+    rng[i] = st;
+    queue_store(q, i, i, r);
+}
+
+// ---- K4 (+K5): one bounce for every live ray, survivors compacted into the next queue ---------------
+// Compaction: wave64 __ballot + mbcnt prefix inside each wave, wave totals combined through LDS,
+// ONE global atomic per 256-thread block (the reference: one per 16 work-items).
+// Terminated paths add clamp(res,0,1) straight into the accumulator (each pixel terminates at most
+// once per sample, so K5's "combined += image" needs no separate pass and no atomics).
+__global__ void __launch_bounds__(256) k_wf_shoot(SceneDev S, QueueDev qin, QueueDev qout,
+                                                   uint32_t* __restrict__ rng, float4* __restrict__ accum,
+                                                   const uint32_t* __restrict__ count_in,
+                                                   uint32_t* __restrict__ count_out, int last_depth) {
+    __shared__ uint32_t wave_total[4];
+    __shared__ uint32_t block_base;
+    const uint32_t n = *count_in;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= n) return; // whole block idle (uniform exit)
+    bool survive = false;
+    RayState r;
+    uint32_t id = 0;
+    if (i < n) {
+        id = queue_load(qin, i, r);
+        uint32_t st = rng[id]; // ScopedRng load (src/render_wavefront.cpp:15-32)
+        f3 res;
+        const bool done = bounce(S, st, r, res);
+        rng[id] = st;          // ScopedRng store
+        if (done) {
+            float4 acc = accum[id];
+            acc.x = acc.x + clamp01(res.x), acc.y = acc.y + clamp01(res.y), acc.z = acc.z + clamp01(res.z);
+            accum[id] = acc;
+        } else {
+            survive = !last_depth; // survivors of the last depth contribute (0,0,0) (:279-280)
+        }
+    }
+    const unsigned long long mask = __ballot(survive);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total ? atomicAdd(count_out, total) : 0u;
+    }
+    __syncthreads();
+    if (survive) {
+        uint32_t slot = block_base + prefix;
+        for (uint32_t w = 0; w < wave; ++w) slot += wave_total[w];
+        queue_store(qout, slot, id, r);
+    }
+}
+
+// ---- K6 + K7: mean over samples, sqrt gamma, fp32 + unorm8 outputs ------------------------------------
+__global__ void __launch_bounds__(256) k_wf_resolve(uint32_t n_local, uint32_t spp, const float4* __restrict__ accum,
+                                                     float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_local) return;
+    const float4 a = accum[i];
+    const float n = (float)spp;
+    const f3 c = mk3(__builtin_sqrtf(a.x / n), __builtin_sqrtf(a.y / n), __builtin_sqrtf(a.z / n));
+    if (out_f32) reinterpret_cast<float4*>(out_f32)[i] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (out_u8)
+        reinterpret_cast<uint32_t*>(out_u8)[i] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+                                                 ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+}
+
+// ---- batch closest-hit query (rt_intersect_batch) and unit probes ------------------------------------
+__global__ void __launch_bounds__(256) k_intersect_batch(SceneDev S, uint32_t n, const float* __restrict__ org,
+                                                          const float* __restrict__ dir, float* __restrict__ t,
+                                                          float* __restrict__ u, float* __restrict__ v,
+                                                          uint32_t* __restrict__ tri) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    t[i] = h.t, u[i] = h.u, v[i] = h.v, tri[i] = h.tri;
+}
+
+__global__ void k_probe_xorshift(uint32_t seed, uint32_t n, float* __restrict__ out, uint32_t* __restrict__ state_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t a = seed;
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng_next(a);
+    *state_out = a;
+}
+
+__global__ void __launch_bounds__(256) k_probe_half(uint32_t n, const float* __restrict__ in, float* __restrict__ out,
+                                                     uint16_t* __restrict__ bits) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint16_t h = f2h(in[i]);
+    bits[i] = h;
+    out[i] = h2f(h);
+}
+
+__global__ void __launch_bounds__(256) k_probe_scatter(SceneDev S, uint32_t material, uint32_t n,
+                                                        const float* __restrict__ dir, const float* __restrict__ normal,
+                                                        const float* __restrict__ uv, const uint32_t* __restrict__ seed,
+                                                        uint8_t* __restrict__ ok, float* __restrict__ out_dir,
+                                                        float* __restrict__ out_att, uint32_t* __restrict__ seed_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t st = seed[i];
+    f3 od, oa;
+    const bool r = scatter(S, S.mats[material], st, mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+                           mk3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]), uv[2 * i], uv[2 * i + 1], od, oa);
+    ok[i] = r ? 1 : 0;
+    out_dir[3 * i] = od.x, out_dir[3 * i + 1] = od.y, out_dir[3 * i + 2] = od.z;
+    out_att[3 * i] = oa.x, out_att[3 * i + 1] = oa.y, out_att[3 * i + 2] = oa.z;
+    seed_out[i] = st;
+}
+
+} // namespace rt

@@ -1,0 +1,546 @@
+// rt_mi355x.hip — implementation of the C ABI in include/rt_mi355x.h on HIP (gfx950).
+//
+// Host orchestration of the two renderers. Unlike the reference, which blocks on the host after
+// every kernel (769 blocking submits per 64-spp frame: src/render_wavefront.cpp:396-431), a frame
+// here is ONE asynchronous stream of launches: queue lengths live in device memory, one counter
+// per (sample, depth), so no bounce ever waits for the host.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_kernels.h"
+#include "scene_build.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,                           \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+int device_ok(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (the render path has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    return RT_OK;
+}
+
+template <typename T>
+int upload(const std::vector<T>& v, const T** out, uint64_t& bytes) {
+    *out = nullptr;
+    const size_t n = std::max<size_t>(v.size(), 1);
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, n * sizeof(T)));
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    bytes += n * sizeof(T);
+    return RT_OK;
+}
+
+} // namespace
+
+struct rt_scene {
+    HostScene hs;
+    int device = -1;
+    SceneDev dev{};
+    uint64_t device_bytes = 0;
+};
+
+struct rt_renderer {
+    int kind = 0;
+    rt_scene* scene = nullptr;
+    int32_t width = 0, height = 0;
+    uint32_t max_depth = 0, spp = 0, seed_mode = 0;
+    TileDev tile{0, 1, 8, 0};
+    uint32_t n_local = 0; // pixels in this tile
+    hipStream_t stream = nullptr;
+    // outputs (device) used when the caller passes host pointers
+    float* d_f32 = nullptr;
+    uint8_t* d_u8 = nullptr;
+    // megakernel
+    unsigned long long* d_ray_counter = nullptr;
+    // wavefront
+    QueueDev q[2]{};
+    uint32_t* d_rng = nullptr;
+    float4* d_accum = nullptr;
+    uint32_t* d_counts = nullptr; // spp * (max_depth + 1)
+    std::vector<uint32_t> h_counts;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool profile_kernels = false;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+void free_tile_buffers(rt_renderer* r) {
+    auto fr = [](auto*& p) {
+        if (p) (void)hipFree((void*)p);
+        p = nullptr;
+    };
+    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_rng), fr(r->d_accum), fr(r->d_counts);
+    for (auto& q : r->q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
+}
+
+int alloc_tile_buffers(rt_renderer* r) {
+    free_tile_buffers(r);
+    int32_t rows = 0;
+    for (int32_t y = 0; y < r->height; ++y)
+        if (((uint32_t)y / r->tile.strip_rows) % r->tile.world == r->tile.rank) rows++;
+    r->tile.local_rows = rows;
+    r->n_local = (uint32_t)rows * (uint32_t)r->width;
+    const size_t n = std::max<size_t>(r->n_local, 1);
+    HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
+    HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
+    if (r->kind == RT_RENDERER_MEGAKERNEL) {
+        HIPCHK(hipMalloc((void**)&r->d_ray_counter, sizeof(unsigned long long)));
+    } else {
+        for (auto& q : r->q) {
+            HIPCHK(hipMalloc((void**)&q.org_id, n * 16));
+            HIPCHK(hipMalloc((void**)&q.a, n * 8));
+            HIPCHK(hipMalloc((void**)&q.b, n * 8));
+            HIPCHK(hipMalloc((void**)&q.c, n * 2 + 2));
+        }
+        HIPCHK(hipMalloc((void**)&r->d_rng, n * 4));
+        HIPCHK(hipMalloc((void**)&r->d_accum, n * 16));
+        const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
+        HIPCHK(hipMalloc((void**)&r->d_counts, nc * 4));
+        r->h_counts.resize(nc);
+    }
+    return RT_OK;
+}
+
+CameraDev to_dev(const rt_camera& c) {
+    CameraDev d;
+    std::memcpy(d.center, c.center, 12), std::memcpy(d.pixel00, c.pixel00, 12);
+    std::memcpy(d.du, c.delta_u, 12), std::memcpy(d.dv, c.delta_v, 12);
+    d.width = c.width, d.height = c.height;
+    return d;
+}
+
+hipEvent_t pool_event(rt_renderer* r, size_t i) {
+    while (r->ev_pool.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        r->ev_pool.push_back(e);
+    }
+    return r->ev_pool[i];
+}
+
+// Enqueues one frame on `st`. Device outputs may be null.
+int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats,
+                  size_t* n_hot_events) {
+    const CameraDev c = to_dev(*cam);
+    const SceneDev& S = r->scene->dev;
+    uint32_t launches = 0;
+    *n_hot_events = 0;
+    if (r->n_local == 0) {
+        if (stats) stats->launches = 0;
+        return RT_OK;
+    }
+    if (r->kind == RT_RENDERER_MEGAKERNEL) {
+        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, sizeof(unsigned long long), st));
+        const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
+        hipEvent_t e0 = pool_event(r, 0), e1 = pool_event(r, 1);
+        if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+        HIPCHK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_megakernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, S, c, r->tile, r->max_depth, r->spp,
+                           r->seed_mode, d_f32, d_u8, r->d_ray_counter);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, st));
+        *n_hot_events = 2;
+        launches = 1;
+    } else {
+        const uint32_t grid = (r->n_local + 255u) / 256u;
+        const uint32_t D = r->max_depth;
+        HIPCHK(hipMemsetAsync(r->d_counts, 0, r->h_counts.size() * 4, st));
+        hipLaunchKernelGGL(k_wf_init, dim3(grid), dim3(256), 0, st, c, r->tile, r->seed_mode, r->n_local, r->d_rng, r->d_accum);
+        launches++;
+        size_t ne = 0;
+        for (uint32_t s = 0; s < r->spp; ++s) {
+            uint32_t* counts = r->d_counts + (size_t)s * (D + 1);
+            uint32_t buf = 0;
+            hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(256), 0, st, c, r->tile, r->n_local, r->d_rng, r->q[buf], counts);
+            launches++;
+            for (uint32_t d = 0; d < D; ++d) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (r->profile_kernels) {
+                    e0 = pool_event(r, ne), e1 = pool_event(r, ne + 1);
+                    if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                    HIPCHK(hipEventRecord(e0, st));
+                }
+                hipLaunchKernelGGL(k_wf_shoot, dim3(grid), dim3(256), 0, st, S, r->q[buf], r->q[buf ^ 1], r->d_rng, r->d_accum,
+                                   counts + d, counts + d + 1, d + 1 == D ? 1 : 0);
+                if (r->profile_kernels) {
+                    HIPCHK(hipEventRecord(e1, st));
+                    ne += 2;
+                }
+                launches++;
+                buf ^= 1;
+            }
+        }
+        *n_hot_events = ne;
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(256), 0, st, r->n_local, r->spp, r->d_accum, d_f32, d_u8);
+        launches++;
+        HIPCHK(hipGetLastError());
+    }
+    if (stats) stats->launches = launches;
+    return RT_OK;
+}
+
+int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats) {
+    if (!r || !cam) return fail(RT_ERR_INVALID, "null renderer or camera");
+    if (cam->width != r->width || cam->height != r->height) return fail(RT_ERR_INVALID, "camera size differs from the renderer's image size");
+    HIPCHK(hipSetDevice(r->scene->device));
+    rt_stats local{};
+    size_t n_hot = 0;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    HIPCHK(hipEventRecord(r->ev_begin, st));
+    int rc = enqueue_frame(r, cam, d_f32, d_u8, st, &local, &n_hot);
+    if (rc != RT_OK) return rc;
+    HIPCHK(hipEventRecord(r->ev_end, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    local.seconds = std::chrono::duration<double>(t1 - t0).count();
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
+    local.device_ms = ms;
+    for (size_t i = 0; i + 1 < n_hot; i += 2) {
+        float k = 0.0f;
+        HIPCHK(hipEventElapsedTime(&k, r->ev_pool[i], r->ev_pool[i + 1]));
+        local.hot_kernel_ms += k;
+        local.hot_kernel_launches++;
+    }
+    if (r->n_local) {
+        if (r->kind == RT_RENDERER_MEGAKERNEL) {
+            unsigned long long rays = 0;
+            HIPCHK(hipMemcpy(&rays, r->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
+            local.rays = rays;
+        } else {
+            HIPCHK(hipMemcpy(r->h_counts.data(), r->d_counts, r->h_counts.size() * 4, hipMemcpyDeviceToHost));
+            uint64_t rays = 0;
+            const uint32_t D = r->max_depth;
+            for (uint32_t s = 0; s < r->spp; ++s)
+                for (uint32_t d = 0; d < D; ++d) rays += r->h_counts[(size_t)s * (D + 1) + d]; // :407
+            local.rays = rays;
+        }
+    }
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+// Camera::Camera (src/camera.hpp:74-106). Host arithmetic, same operation order as the reference's
+// constructor: normalize, two cross products, viewport (aspect, 1), pixel00, per-pixel deltas.
+int rt_camera_init(rt_camera* out, int32_t width, int32_t height, const float center[3], const float dir_in[3],
+                   float focal_length) {
+    if (!out || !center || !dir_in || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad camera arguments");
+    auto norm = [](const float v[3], float o[3]) {
+        float inv = 1.0f / std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        o[0] = v[0] * inv, o[1] = v[1] * inv, o[2] = v[2] * inv;
+    };
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    float dir[3], right[3], up[3], tmp[3];
+    const float world_up[3] = {0.0f, 1.0f, 0.0f};
+    norm(dir_in, dir);
+    cross(dir, world_up, tmp), norm(tmp, right);
+    cross(right, dir, tmp), norm(tmp, up);
+    const float vp0 = 1.0f * ((float)width / (float)height), vp1 = 1.0f;
+    const float du_div = (float)width / (vp0 * 2.0f), dv_div = (float)height / (vp1 * 2.0f);
+    for (int a = 0; a < 3; ++a) {
+        const float viewport_u = (-right[a]) * vp0, viewport_v = up[a] * vp1;
+        out->center[a] = center[a];
+        out->pixel00[a] = ((center[a] + viewport_u) + viewport_v) + dir[a] * focal_length;
+        out->delta_u[a] = right[a] / du_div;
+        out->delta_v[a] = (-up[a]) / dv_div;
+    }
+    out->width = width, out->height = height;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_OOM, "host allocation failed");
+    std::string err;
+    int rc = RT_OK;
+    try {
+        rc = build_host_scene(desc, bvh_kind, s->hs, err);
+    } catch (const std::bad_alloc&) {
+        delete s;
+        return fail(RT_ERR_OOM, "host allocation failed while building the scene");
+    }
+    if (rc != RT_OK) {
+        delete s;
+        return fail(rc, err);
+    }
+    s->device = device;
+    if (device >= 0) {
+        rc = device_ok(device);
+        if (rc == RT_OK) rc = upload(s->hs.nodes, &s->dev.nodes, s->device_bytes);
+        if (rc == RT_OK) rc = upload(s->hs.tris, &s->dev.tris, s->device_bytes);
+        if (rc == RT_OK) rc = upload(s->hs.shade, &s->dev.shade, s->device_bytes);
+        if (rc == RT_OK) rc = upload(s->hs.inst, &s->dev.inst, s->device_bytes);
+        if (rc == RT_OK) rc = upload(s->hs.mats, &s->dev.mats, s->device_bytes);
+        if (rc == RT_OK) rc = upload(s->hs.tex, &s->dev.tex, s->device_bytes);
+        if (rc != RT_OK) {
+            rt_scene_destroy(s);
+            return rc;
+        }
+        s->dev.n_nodes = (uint32_t)s->hs.nodes.size();
+        s->dev.n_tris = (uint32_t)(s->hs.wverts.size() / 9);
+        std::memcpy(s->dev.sky, s->hs.sky, 12);
+    }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
+        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
+        (void)hipFree((void*)s->dev.inst), (void)hipFree((void*)s->dev.mats), (void)hipFree((void*)s->dev.tex);
+    }
+    delete s;
+}
+
+int rt_scene_info(const rt_scene* s, rt_scene_info_t* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    out->n_triangles = (uint32_t)(s->hs.wverts.size() / 9);
+    out->n_nodes = (uint32_t)s->hs.nodes.size();
+    out->max_depth = s->hs.max_depth;
+    out->max_leaf_tris = s->hs.max_leaf_tris;
+    std::memcpy(out->bounds_lo, s->hs.bounds_lo, 12), std::memcpy(out->bounds_hi, s->hs.bounds_hi, 12);
+    out->sah_cost = s->hs.sah_cost;
+    out->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+
+int rt_scene_check_bvh(const rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    std::string err;
+    int rc = check_bvh(s->hs, err);
+    return rc == RT_OK ? RT_OK : fail(rc, err);
+}
+
+int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* dir, float* t, float* u, float* v,
+                       uint32_t* tri) {
+    if (!s || (n && (!org || !dir || !t || !u || !v || !tri))) return fail(RT_ERR_INVALID, "null argument");
+    if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    float *d_org = nullptr, *d_dir = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_org, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_dir, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 16));
+    HIPCHK(hipMemcpy(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    float* d_t = d_out;
+    float* d_u = d_out + n;
+    float* d_v = d_out + 2 * (size_t)n;
+    uint32_t* d_tri = (uint32_t*)(d_out + 3 * (size_t)n);
+    hipLaunchKernelGGL(k_intersect_batch, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, n, d_org, d_dir, d_t, d_u, d_v, d_tri);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(u, d_u, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(v, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_org), (void)hipFree(d_dir), (void)hipFree(d_out);
+    return RT_OK;
+}
+
+int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height, uint32_t max_depth,
+                       uint32_t sample_count, uint32_t seed_mode, rt_renderer** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    if (!scene) return fail(RT_ERR_INVALID, "null scene");
+    if (kind != RT_RENDERER_MEGAKERNEL && kind != RT_RENDERER_WAVEFRONT) return fail(RT_ERR_INVALID, "unknown renderer kind");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(RT_ERR_INVALID, "bad image size");
+    if (sample_count == 0) return fail(RT_ERR_INVALID, "sample_count must be >= 1");
+    if (seed_mode > RT_SEED_MEGAKERNEL) return fail(RT_ERR_INVALID, "unknown seed mode");
+    if ((uint64_t)sample_count * ((uint64_t)max_depth + 1) > (1ull << 26)) return fail(RT_ERR_INVALID, "sample_count * max_depth too large");
+    if (scene->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
+    int rc = device_ok(scene->device);
+    if (rc != RT_OK) return rc;
+    rt_renderer* r = new (std::nothrow) rt_renderer();
+    if (!r) return fail(RT_ERR_OOM, "host allocation failed");
+    r->kind = kind, r->scene = scene, r->width = width, r->height = height;
+    r->max_depth = max_depth, r->spp = sample_count;
+    r->seed_mode = seed_mode != RT_SEED_DEFAULT ? seed_mode
+                   : (kind == RT_RENDERER_MEGAKERNEL ? RT_SEED_MEGAKERNEL : RT_SEED_WAVEFRONT);
+    const char* prof = std::getenv("RT_PROFILE_KERNELS");
+    r->profile_kernels = prof && prof[0] == '1';
+    auto bail = [&](int code) {
+        rt_renderer_destroy(r);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess)
+        return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+    rc = alloc_tile_buffers(r);
+    if (rc != RT_OK) return bail(rc);
+    *out = r;
+    return RT_OK;
+}
+
+void rt_renderer_destroy(rt_renderer* r) {
+    if (!r) return;
+    if (r->scene && hipSetDevice(r->scene->device) == hipSuccess) {
+        if (r->stream) (void)hipStreamSynchronize(r->stream);
+        free_tile_buffers(r);
+        for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
+        if (r->ev_begin) (void)hipEventDestroy(r->ev_begin);
+        if (r->ev_end) (void)hipEventDestroy(r->ev_end);
+        if (r->stream) (void)hipStreamDestroy(r->stream);
+    }
+    delete r;
+}
+
+int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t strip_rows) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    if (world == 0 || rank >= world || strip_rows == 0) return fail(RT_ERR_INVALID, "bad tile split");
+    HIPCHK(hipSetDevice(r->scene->device));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
+    return alloc_tile_buffers(r);
+}
+
+int32_t rt_renderer_local_rows(const rt_renderer* r) { return r ? r->tile.local_rows : 0; }
+
+int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row) {
+    if (!r || local_row < 0 || local_row >= r->tile.local_rows) return -1;
+    const uint32_t strip = (uint32_t)local_row / r->tile.strip_rows, within = (uint32_t)local_row % r->tile.strip_rows;
+    return (int32_t)((strip * r->tile.world + r->tile.rank) * r->tile.strip_rows + within);
+}
+
+int rt_renderer_set_profiling(rt_renderer* r, int enable) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    r->profile_kernels = enable != 0;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8, rt_stats* stats) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    int rc = render_impl(r, cam, rgba_f32 ? r->d_f32 : nullptr, rgba_u8 ? r->d_u8 : nullptr, r->stream, stats);
+    if (rc != RT_OK) return rc;
+    if (rgba_f32 && r->n_local) HIPCHK(hipMemcpy(rgba_f32, r->d_f32, (size_t)r->n_local * 16, hipMemcpyDeviceToHost));
+    if (rgba_u8 && r->n_local) HIPCHK(hipMemcpy(rgba_u8, r->d_u8, (size_t)r->n_local * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream,
+                           rt_stats* stats) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    return render_impl(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream, stats);
+}
+
+int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out) {
+    if (!out || !state_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
+    int rc = device_ok(device);
+    if (rc != RT_OK) return rc;
+    float* d_out = nullptr;
+    uint32_t* d_st = nullptr;
+    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_st, 4));
+    hipLaunchKernelGGL(k_probe_xorshift, dim3(1), dim3(64), 0, 0, seed, n, d_out, d_st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(state_out, d_st, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_out), (void)hipFree(d_st);
+    return RT_OK;
+}
+
+int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out, uint16_t* bits_out) {
+    if (!in || !out || !bits_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
+    int rc = device_ok(device);
+    if (rc != RT_OK) return rc;
+    float *d_in = nullptr, *d_out = nullptr;
+    uint16_t* d_bits = nullptr;
+    HIPCHK(hipMalloc((void**)&d_in, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_bits, (size_t)n * 2));
+    HIPCHK(hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_half, dim3((n + 255u) / 256u), dim3(256), 0, 0, n, d_in, d_out, d_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bits_out, d_bits, (size_t)n * 2, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_bits);
+    return RT_OK;
+}
+
+int rt_probe_scatter(rt_scene* s, uint32_t material, uint32_t n, const float* dir, const float* normal, const float* uv,
+                     const uint32_t* seed, uint8_t* ok, float* out_dir, float* out_att, uint32_t* seed_out) {
+    if (!s || !dir || !normal || !uv || !seed || !ok || !out_dir || !out_att || !seed_out || n == 0)
+        return fail(RT_ERR_INVALID, "bad arguments");
+    if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
+    if (material >= s->hs.mats.size()) return fail(RT_ERR_INVALID, "material index out of range");
+    HIPCHK(hipSetDevice(s->device));
+    float *d_dir, *d_nrm, *d_uv, *d_od, *d_oa;
+    uint32_t *d_seed, *d_so;
+    uint8_t* d_ok;
+    HIPCHK(hipMalloc((void**)&d_dir, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_nrm, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_uv, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&d_od, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_oa, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&d_seed, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_so, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_ok, (size_t)n));
+    HIPCHK(hipMemcpy(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_nrm, normal, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_uv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_seed, seed, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_scatter, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, material, n, d_dir, d_nrm, d_uv,
+                       d_seed, d_ok, d_od, d_oa, d_so);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_dir, d_od, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_att, d_oa, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(seed_out, d_so, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_dir), (void)hipFree(d_nrm), (void)hipFree(d_uv), (void)hipFree(d_od), (void)hipFree(d_oa);
+    (void)hipFree(d_seed), (void)hipFree(d_so), (void)hipFree(d_ok);
+    return RT_OK;
+}
+
+} // extern "C"

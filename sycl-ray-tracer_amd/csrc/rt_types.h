@@ -1,0 +1,95 @@
+// rt_types.h — data layouts of the device-resident scene and of the kernel parameter block.
+// Shared by the host builder (scene_build.cpp) and the HIP kernels (rt_kernels.hip).
+#pragma once
+#include <cstdint>
+
+namespace rt {
+
+// ---- BVH ----------------------------------------------------------------------------------------
+// 64-byte node holding the boxes of BOTH children, so one 4 x dwordx4 fetch decides a traversal
+// step. Bounds are interleaved per axis: bx = (lo0.x, hi0.x, lo1.x, hi1.x), by, bz likewise.
+// child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 2) | (count - 1), with
+// `first` indexing the leaf-ordered triangle array and 1 <= count <= 4. An absent child (scenes
+// with fewer than two leaves) has an inverted box (lo = +inf, hi = -inf) that no ray can enter.
+struct alignas(64) BvhNode {
+    float bx[4];
+    float by[4];
+    float bz[4];
+    int32_t child[2];
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+constexpr int kMaxLeafTris = 4;
+constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64
+constexpr uint32_t kNoTri = 0xFFFFFFFFu;
+constexpr float kTNear = 0.0001f;   // RayData::to_embree tnear (src/camera.hpp:50)
+
+// ---- triangles, leaf order: 48 bytes = 3 x float4 -------------------------------------------------
+//   a = (v0.x, v0.y, v0.z, e1.x)  b = (e1.y, e1.z, e2.x, e2.y)  c = (e2.z, bits(global index), 0, 0)
+struct alignas(16) TriRec {
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    uint32_t global_index; // triangle index in rt_scene_desc order (tie-break + shading lookup)
+    uint32_t pad[2];
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// ---- per-triangle shading attributes, GLOBAL order: 64 bytes ------------------------------------
+// What trace_ray gathers through index_buffer/normal_buffer/uv_buffer (src/trace_ray.hpp:34-45),
+// pre-gathered per triangle so a hit costs one aligned 64-byte fetch instead of a dependent chain.
+struct alignas(64) ShadeRec {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    uint32_t instance;
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec must be 64 bytes");
+
+// GeometryData::obj_to_world + material id (src/scene.hpp:17-24): 48 bytes
+struct alignas(16) InstRec {
+    float normal_mat[9]; // column-major 3x3
+    uint32_t material;
+    uint32_t pad[2];
+};
+static_assert(sizeof(InstRec) == 48, "InstRec must be 48 bytes");
+
+// Material (src/material.hpp:163-238): 48 bytes
+struct alignas(16) MatRec {
+    uint32_t type;
+    uint32_t tex_kind;
+    float color[3];
+    uint32_t tex_layer;
+    float emissive[3];
+    float roughness;
+    float ior;
+    uint32_t pad;
+};
+static_assert(sizeof(MatRec) == 48, "MatRec must be 48 bytes");
+
+// device pointers of one scene replica
+struct SceneDev {
+    const BvhNode* nodes;
+    const TriRec* tris;
+    const ShadeRec* shade;
+    const InstRec* inst;
+    const MatRec* mats;
+    const uint8_t* tex; // n_layers x 512 x 512 x 4
+    uint32_t n_nodes;
+    uint32_t n_tris;
+    float sky[3];
+};
+
+// == Camera POD (src/camera.hpp:65-72)
+struct CameraDev {
+    float center[3], pixel00[3], du[3], dv[3];
+    int32_t width, height;
+};
+
+// image-space tile owned by this renderer (strips of `strip_rows` rows, strip k -> rank k % world)
+struct TileDev {
+    uint32_t rank, world, strip_rows;
+    int32_t local_rows;
+};
+
+} // namespace rt

@@ -1,0 +1,469 @@
+// scene_build.cpp — host side of rt_scene_create: validation, instance flattening, BVH build.
+//
+// Replaces what Embree does behind rtcCommitScene for the reference (src/scene.cpp:101-107,
+// 406-439,487-507): a two-level instanced triangle BVH becomes ONE flattened world-space BVH2
+// over all instance triangles. The image does not depend on the tree (closest t, ties to the
+// lowest global triangle index), so the builder is free to optimise for traversal speed.
+//
+// Compiled with -ffp-contract=off: the world-space vertices and edges computed here are part of
+// the arithmetic contract shared with the CPU oracle (instance transform row order, e1 = v1 - v0).
+#include "scene_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+namespace rt {
+namespace {
+
+struct GNode { // generic build node
+    float lo[3], hi[3];
+    int32_t left = -1, right = -1; // inner: both >= 0
+    uint32_t first = 0, count = 0; // range in `order`
+    uint32_t depth = 0;
+};
+
+struct Builder {
+    const std::vector<float>& wv; // 9 per triangle
+    std::vector<uint32_t> order;
+    std::vector<GNode> nodes;
+    std::vector<float> cent; // 3 per triangle
+    std::vector<float> tlo, thi; // per-triangle boxes
+
+    explicit Builder(const std::vector<float>& w) : wv(w) {
+        const size_t n = w.size() / 9;
+        order.resize(n);
+        cent.resize(3 * n);
+        tlo.resize(3 * n);
+        thi.resize(3 * n);
+        for (size_t t = 0; t < n; ++t) {
+            order[t] = (uint32_t)t;
+            for (int a = 0; a < 3; ++a) {
+                float p0 = w[9 * t + a], p1 = w[9 * t + 3 + a], p2 = w[9 * t + 6 + a];
+                tlo[3 * t + a] = std::min(p0, std::min(p1, p2));
+                thi[3 * t + a] = std::max(p0, std::max(p1, p2));
+                cent[3 * t + a] = 0.5f * (tlo[3 * t + a] + thi[3 * t + a]);
+            }
+        }
+    }
+
+    void range_bounds(uint32_t first, uint32_t count, float* lo, float* hi, float* clo, float* chi) const {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = clo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = chi[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (uint32_t k = 0; k < count; ++k) {
+            uint32_t t = order[first + k];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], tlo[3 * t + a]);
+                hi[a] = std::max(hi[a], thi[3 * t + a]);
+                clo[a] = std::min(clo[a], cent[3 * t + a]);
+                chi[a] = std::max(chi[a], cent[3 * t + a]);
+            }
+        }
+    }
+};
+
+inline float half_area(const float* lo, const float* hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// ---- LBVH: 63-bit Morton order + top-down split at the highest differing bit -----------------------
+inline uint64_t expand21(uint64_t v) { // spread the low 21 bits to every third bit
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+void build_lbvh(Builder& b) {
+    const uint32_t n = (uint32_t)b.order.size();
+    float lo[3], hi[3], clo[3], chi[3];
+    b.range_bounds(0, n, lo, hi, clo, chi);
+    std::vector<std::pair<uint64_t, uint32_t>> keys(n);
+    for (uint32_t t = 0; t < n; ++t) {
+        uint64_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            double ext = (double)chi[a] - (double)clo[a];
+            double f = ext > 0 ? ((double)b.cent[3 * t + a] - (double)clo[a]) / ext : 0.0;
+            uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, f * 2097152.0));
+            code |= expand21(q) << (2 - a);
+        }
+        keys[t] = {code, t};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (uint32_t i = 0; i < n; ++i) b.order[i] = keys[i].second;
+
+    struct Work {
+        int32_t node;
+        uint32_t first, count, depth;
+    };
+    std::vector<Work> todo;
+    b.nodes.clear();
+    b.nodes.push_back(GNode{});
+    todo.push_back({0, 0, n, 0});
+    while (!todo.empty()) {
+        Work w = todo.back();
+        todo.pop_back();
+        GNode nd;
+        float c0[3], c1[3];
+        b.range_bounds(w.first, w.count, nd.lo, nd.hi, c0, c1);
+        nd.first = w.first, nd.count = w.count, nd.depth = w.depth;
+        if (w.count > (uint32_t)kMaxLeafTris) {
+            uint64_t ka = keys[w.first].first, kb = keys[w.first + w.count - 1].first;
+            uint32_t split;
+            if (ka == kb || w.depth >= 56) {
+                split = w.count / 2; // identical codes (or runaway depth): halve the index range
+            } else {
+                int bit = 63 - __builtin_clzll(ka ^ kb);
+                uint64_t mask = 1ull << bit;
+                // first element whose `bit` is set (codes share all higher bits, so it is monotone)
+                uint32_t l = 0, r = w.count;
+                while (l < r) {
+                    uint32_t m = (l + r) / 2;
+                    if (keys[w.first + m].first & mask) r = m; else l = m + 1;
+                }
+                split = l;
+                if (split == 0 || split == w.count) split = w.count / 2;
+            }
+            nd.left = (int32_t)b.nodes.size();
+            nd.right = nd.left + 1;
+            b.nodes.push_back(GNode{});
+            b.nodes.push_back(GNode{});
+            todo.push_back({nd.left, w.first, split, w.depth + 1});
+            todo.push_back({nd.right, w.first + split, w.count - split, w.depth + 1});
+        }
+        b.nodes[w.node] = nd;
+    }
+}
+
+// ---- binned SAH, top-down -------------------------------------------------------------------------
+void build_sah(Builder& b) {
+    const uint32_t n = (uint32_t)b.order.size();
+    constexpr int NB = 32;
+    struct Work {
+        int32_t node;
+        uint32_t first, count, depth;
+    };
+    std::vector<Work> todo;
+    b.nodes.clear();
+    b.nodes.push_back(GNode{});
+    todo.push_back({0, 0, n, 0});
+    std::vector<uint32_t> tmp;
+    while (!todo.empty()) {
+        Work w = todo.back();
+        todo.pop_back();
+        GNode nd;
+        float clo[3], chi[3];
+        b.range_bounds(w.first, w.count, nd.lo, nd.hi, clo, chi);
+        nd.first = w.first, nd.count = w.count, nd.depth = w.depth;
+        bool make_leaf = w.count == 1;
+        uint32_t split = 0;
+        if (!make_leaf) {
+            const float parent_area = half_area(nd.lo, nd.hi);
+            float best_cost = std::numeric_limits<float>::infinity();
+            int best_axis = -1, best_bin = -1;
+            if (w.depth < 48) {
+                for (int a = 0; a < 3; ++a) {
+                    float ext = chi[a] - clo[a];
+                    if (!(ext > 0.0f)) continue;
+                    float scale = (float)NB / ext;
+                    uint32_t cnt[NB] = {0};
+                    float blo[NB][3], bhi[NB][3];
+                    for (int i = 0; i < NB; ++i)
+                        for (int k = 0; k < 3; ++k) blo[i][k] = INFINITY, bhi[i][k] = -INFINITY;
+                    for (uint32_t k = 0; k < w.count; ++k) {
+                        uint32_t t = b.order[w.first + k];
+                        int bi = std::min(NB - 1, std::max(0, (int)((b.cent[3 * t + a] - clo[a]) * scale)));
+                        cnt[bi]++;
+                        for (int j = 0; j < 3; ++j) {
+                            blo[bi][j] = std::min(blo[bi][j], b.tlo[3 * t + j]);
+                            bhi[bi][j] = std::max(bhi[bi][j], b.thi[3 * t + j]);
+                        }
+                    }
+                    float ra[NB];
+                    uint32_t rc[NB];
+                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    uint32_t c = 0;
+                    for (int i = NB - 1; i > 0; --i) {
+                        c += cnt[i];
+                        for (int j = 0; j < 3; ++j) lo[j] = std::min(lo[j], blo[i][j]), hi[j] = std::max(hi[j], bhi[i][j]);
+                        ra[i] = half_area(lo, hi), rc[i] = c;
+                    }
+                    for (int j = 0; j < 3; ++j) lo[j] = INFINITY, hi[j] = -INFINITY;
+                    c = 0;
+                    for (int i = 0; i < NB - 1; ++i) {
+                        c += cnt[i];
+                        for (int j = 0; j < 3; ++j) lo[j] = std::min(lo[j], blo[i][j]), hi[j] = std::max(hi[j], bhi[i][j]);
+                        if (c == 0 || rc[i + 1] == 0) continue;
+                        float cost = half_area(lo, hi) * (float)c + ra[i + 1] * (float)rc[i + 1];
+                        if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = i;
+                    }
+                }
+            }
+            // leaf cost = count * area; split cost = 1 traversal step * area + children
+            if (w.count <= (uint32_t)kMaxLeafTris &&
+                !(best_axis >= 0 && best_cost + 1.0f * parent_area < (float)w.count * parent_area)) {
+                make_leaf = true;
+            } else if (best_axis >= 0) {
+                float ext = chi[best_axis] - clo[best_axis];
+                float scale = (float)NB / ext;
+                auto mid = std::partition(b.order.begin() + w.first, b.order.begin() + w.first + w.count, [&](uint32_t t) {
+                    int bi = std::min(NB - 1, std::max(0, (int)((b.cent[3 * t + best_axis] - clo[best_axis]) * scale)));
+                    return bi <= best_bin;
+                });
+                split = (uint32_t)(mid - (b.order.begin() + w.first));
+            }
+            if (!make_leaf && (split == 0 || split == w.count)) {
+                // all centroids coincide (or depth guard): median split on the index order
+                split = w.count / 2;
+                std::nth_element(b.order.begin() + w.first, b.order.begin() + w.first + split,
+                                 b.order.begin() + w.first + w.count);
+            }
+        }
+        if (!make_leaf) {
+            nd.left = (int32_t)b.nodes.size();
+            nd.right = nd.left + 1;
+            b.nodes.push_back(GNode{});
+            b.nodes.push_back(GNode{});
+            todo.push_back({nd.left, w.first, split, w.depth + 1});
+            todo.push_back({nd.right, w.first + split, w.count - split, w.depth + 1});
+        }
+        b.nodes[w.node] = nd;
+    }
+}
+
+inline void set_child_box(BvhNode& n, int c, const float* lo, const float* hi, float pad) {
+    n.bx[2 * c] = lo[0] - pad, n.bx[2 * c + 1] = hi[0] + pad;
+    n.by[2 * c] = lo[1] - pad, n.by[2 * c + 1] = hi[1] + pad;
+    n.bz[2 * c] = lo[2] - pad, n.bz[2 * c + 1] = hi[2] + pad;
+}
+inline void set_absent(BvhNode& n, int c) {
+    const float inf = std::numeric_limits<float>::infinity();
+    n.bx[2 * c] = n.by[2 * c] = n.bz[2 * c] = inf;
+    n.bx[2 * c + 1] = n.by[2 * c + 1] = n.bz[2 * c + 1] = -inf;
+    n.child[c] = ~0; // leaf(first 0, count 1); unreachable behind the inverted box
+}
+
+} // namespace
+
+int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::string& err) {
+    if (!d) { err = "null scene description"; return RT_ERR_INVALID; }
+    if (d->n_triangles && (!d->positions || !d->normals || !d->uvs || !d->indices || !d->tri_instance)) {
+        err = "null geometry array"; return RT_ERR_INVALID;
+    }
+    if ((d->n_instances && !d->instances) || (d->n_materials && !d->materials)) {
+        err = "null instance/material array"; return RT_ERR_INVALID;
+    }
+    if (d->n_layers > RT_TEX_MAX_LAYERS) { err = "more than 128 texture layers"; return RT_ERR_INVALID; }
+    if (d->n_layers && !d->textures) { err = "null texture array"; return RT_ERR_INVALID; }
+    if (d->n_triangles >= (1u << 28)) { err = "too many triangles (limit 2^28)"; return RT_ERR_INVALID; }
+    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH) {
+        err = "unknown bvh_kind"; return RT_ERR_INVALID;
+    }
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        if (d->instances[i].material >= d->n_materials) { err = "instance material out of range"; return RT_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material& m = d->materials[i];
+        if (m.type > RT_MAT_DIELECTRIC || m.tex_kind > RT_TEX_IMAGE) { err = "bad material type"; return RT_ERR_INVALID; }
+        if (m.tex_kind == RT_TEX_IMAGE && m.type != RT_MAT_DIELECTRIC && m.type != RT_MAT_NONE &&
+            m.tex_layer >= d->n_layers) { err = "material texture layer out of range"; return RT_ERR_INVALID; }
+    }
+    const uint32_t T = d->n_triangles;
+    for (uint32_t t = 0; t < T; ++t) {
+        if (d->tri_instance[t] >= d->n_instances) { err = "tri_instance out of range"; return RT_ERR_INVALID; }
+        for (int k = 0; k < 3; ++k)
+            if (d->indices[3 * t + k] >= d->n_vertices) { err = "vertex index out of range"; return RT_ERR_INVALID; }
+    }
+
+    hs = HostScene{};
+    hs.sky[0] = d->sky[0], hs.sky[1] = d->sky[1], hs.sky[2] = d->sky[2];
+    hs.n_layers = d->n_layers;
+    if (d->n_layers) hs.tex.assign(d->textures, d->textures + (size_t)d->n_layers * 512u * 512u * 4u);
+    hs.inst.resize(d->n_instances);
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        std::memcpy(hs.inst[i].normal_mat, d->instances[i].normal_mat, sizeof(float) * 9);
+        hs.inst[i].material = d->instances[i].material;
+        hs.inst[i].pad[0] = hs.inst[i].pad[1] = 0;
+    }
+    hs.mats.resize(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material& m = d->materials[i];
+        MatRec& r = hs.mats[i];
+        r.type = m.type, r.tex_kind = m.tex_kind, r.tex_layer = m.tex_layer;
+        std::memcpy(r.color, m.color, 12), std::memcpy(r.emissive, m.emissive, 12);
+        r.roughness = m.roughness, r.ior = m.ior, r.pad = 0;
+    }
+
+    // flatten: world = ((m0*x + m4*y) + m8*z) + m12 per row of the column-major instance matrix
+    hs.wverts.resize(9 * (size_t)T);
+    hs.shade.resize(T);
+    std::vector<TriRec> gtris(T);
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t ii = d->tri_instance[t];
+        const float* m = d->instances[ii].transform;
+        float p[3][3];
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t vi = d->indices[3 * t + k];
+            const float x = d->positions[3 * vi], y = d->positions[3 * vi + 1], z = d->positions[3 * vi + 2];
+            p[k][0] = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+            p[k][1] = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+            p[k][2] = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+            for (int a = 0; a < 3; ++a) hs.wverts[9 * (size_t)t + 3 * k + a] = p[k][a];
+        }
+        TriRec& tr = gtris[t];
+        for (int a = 0; a < 3; ++a) {
+            tr.v0[a] = p[0][a];
+            tr.e1[a] = p[1][a] - p[0][a];
+            tr.e2[a] = p[2][a] - p[0][a];
+        }
+        tr.global_index = t, tr.pad[0] = tr.pad[1] = 0;
+        ShadeRec& s = hs.shade[t];
+        const uint32_t i0 = d->indices[3 * t], i1 = d->indices[3 * t + 1], i2 = d->indices[3 * t + 2];
+        std::memcpy(s.n0, d->normals + 3 * i0, 12), std::memcpy(s.n1, d->normals + 3 * i1, 12);
+        std::memcpy(s.n2, d->normals + 3 * i2, 12);
+        std::memcpy(s.uv0, d->uvs + 2 * i0, 8), std::memcpy(s.uv1, d->uvs + 2 * i1, 8);
+        std::memcpy(s.uv2, d->uvs + 2 * i2, 8);
+        s.instance = ii;
+    }
+    for (size_t i = 0; i < hs.wverts.size(); ++i) {
+        if (!std::isfinite(hs.wverts[i])) { err = "non-finite world-space vertex"; return RT_ERR_INVALID; }
+    }
+
+    BvhNode root{};
+    set_absent(root, 0), set_absent(root, 1);
+    root.pad[0] = root.pad[1] = 0;
+    if (T == 0) {
+        hs.nodes.assign(1, root);
+        hs.tris.assign(1, TriRec{}); // one dummy record so device pointers are never null
+        hs.tris[0].global_index = kNoTri;
+        return RT_OK;
+    }
+
+    Builder b(hs.wverts);
+    if (bvh_kind == RT_BVH_LBVH) build_lbvh(b); else build_sah(b);
+
+    const GNode& g0 = b.nodes[0];
+    for (int a = 0; a < 3; ++a) hs.bounds_lo[a] = g0.lo[a], hs.bounds_hi[a] = g0.hi[a];
+    float ext = 0.0f, amax = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::max(ext, g0.hi[a] - g0.lo[a]);
+        amax = std::max(amax, std::max(std::fabs(g0.lo[a]), std::fabs(g0.hi[a])));
+    }
+    // Absolute padding of every box: 2e-5 x scene scale. Float rounding of the slab test and of the
+    // Moller-Trumbore t is ~1e-7 x scale, so a padded box can only cull triangles the exact test
+    // would also miss ("culling is conservative").
+    hs.pad = 2e-5f * std::max(ext, amax) + 1e-30f;
+
+    // emit in breadth-first order (top levels contiguous -> LDS staging of the first N nodes)
+    hs.tris.clear();
+    hs.tris.reserve(T);
+    hs.nodes.clear();
+    auto leaf_code = [&](const GNode& g) -> int32_t {
+        uint32_t first = (uint32_t)hs.tris.size();
+        for (uint32_t k = 0; k < g.count; ++k) hs.tris.push_back(gtris[b.order[g.first + k]]);
+        hs.max_leaf_tris = std::max(hs.max_leaf_tris, g.count);
+        hs.max_depth = std::max(hs.max_depth, g.depth);
+        return ~(int32_t)((first << 2) | (g.count - 1));
+    };
+    const double root_area = std::max(1e-30, (double)half_area(g0.lo, g0.hi));
+    double cost = 0.0;
+    if (g0.left < 0) {
+        if (g0.count > (uint32_t)kMaxLeafTris) { err = "internal: oversized root leaf"; return RT_ERR_INVALID; }
+        set_child_box(root, 0, g0.lo, g0.hi, hs.pad);
+        root.child[0] = leaf_code(g0);
+        hs.nodes.push_back(root);
+        hs.sah_cost = (double)g0.count;
+        return RT_OK;
+    }
+    std::queue<std::pair<int32_t, int32_t>> q; // (generic node, output slot)
+    hs.nodes.push_back(BvhNode{});
+    q.push({0, 0});
+    while (!q.empty()) {
+        auto [gi, slot] = q.front();
+        q.pop();
+        const GNode& g = b.nodes[gi];
+        cost += (double)half_area(g.lo, g.hi) / root_area;
+        BvhNode out{};
+        out.pad[0] = out.pad[1] = 0;
+        const int32_t kids[2] = {g.left, g.right};
+        for (int c = 0; c < 2; ++c) {
+            const GNode& k = b.nodes[kids[c]];
+            set_child_box(out, c, k.lo, k.hi, hs.pad);
+            if (k.left < 0) {
+                if (k.count == 0 || k.count > (uint32_t)kMaxLeafTris) { err = "internal: bad leaf size"; return RT_ERR_INVALID; }
+                out.child[c] = leaf_code(k);
+                cost += (double)half_area(k.lo, k.hi) / root_area * (double)k.count;
+            } else {
+                out.child[c] = (int32_t)hs.nodes.size();
+                hs.nodes.push_back(BvhNode{});
+                q.push({kids[c], out.child[c]});
+            }
+        }
+        hs.nodes[slot] = out;
+    }
+    hs.sah_cost = cost;
+    if (hs.tris.size() != T) { err = "internal: triangle count mismatch after build"; return RT_ERR_INVALID; }
+    if (hs.max_depth + 1 >= (uint32_t)kStackSize) { err = "internal: BVH deeper than the traversal stack"; return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+int check_bvh(const HostScene& hs, std::string& err) {
+    const size_t T = hs.wverts.size() / 9;
+    if (hs.nodes.empty()) { err = "no root node"; return RT_ERR_INVALID; }
+    std::vector<uint8_t> seen(T, 0);
+    struct Item { int32_t child; float lo[3], hi[3]; uint32_t depth; };
+    std::vector<Item> st;
+    const float inf = std::numeric_limits<float>::infinity();
+    st.push_back(Item{0, {-inf, -inf, -inf}, {inf, inf, inf}, 0});
+    size_t visited = 0;
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        if (it.depth >= (uint32_t)kStackSize) { err = "tree deeper than traversal stack"; return RT_ERR_INVALID; }
+        if (it.child >= 0) {
+            if ((size_t)it.child >= hs.nodes.size()) { err = "child index out of range"; return RT_ERR_INVALID; }
+            if (++visited > hs.nodes.size()) { err = "cycle in node graph"; return RT_ERR_INVALID; }
+            const BvhNode& n = hs.nodes[it.child];
+            for (int c = 0; c < 2; ++c) {
+                Item k;
+                k.child = n.child[c];
+                k.lo[0] = n.bx[2 * c], k.hi[0] = n.bx[2 * c + 1];
+                k.lo[1] = n.by[2 * c], k.hi[1] = n.by[2 * c + 1];
+                k.lo[2] = n.bz[2 * c], k.hi[2] = n.bz[2 * c + 1];
+                k.depth = it.depth + 1;
+                if (k.lo[0] > k.hi[0]) continue; // absent child
+                for (int a = 0; a < 3; ++a)
+                    if (k.lo[a] < it.lo[a] || k.hi[a] > it.hi[a]) { err = "child box escapes its parent"; return RT_ERR_INVALID; }
+                st.push_back(k);
+            }
+        } else {
+            uint32_t code = (uint32_t)~it.child;
+            uint32_t first = code >> 2, count = (code & 3u) + 1u;
+            if ((size_t)first + count > hs.tris.size()) { err = "leaf range out of bounds"; return RT_ERR_INVALID; }
+            for (uint32_t k = 0; k < count; ++k) {
+                const TriRec& tr = hs.tris[first + k];
+                if (tr.global_index >= T) { err = "leaf triangle has bad global index"; return RT_ERR_INVALID; }
+                if (seen[tr.global_index]++) { err = "triangle appears in two leaves"; return RT_ERR_INVALID; }
+                const float* w = &hs.wverts[9 * (size_t)tr.global_index];
+                for (int v = 0; v < 3; ++v)
+                    for (int a = 0; a < 3; ++a)
+                        if (w[3 * v + a] < it.lo[a] || w[3 * v + a] > it.hi[a]) { err = "triangle vertex outside its leaf box"; return RT_ERR_INVALID; }
+                if (tr.v0[0] != w[0] || tr.v0[1] != w[1] || tr.v0[2] != w[2]) { err = "leaf triangle data mismatch"; return RT_ERR_INVALID; }
+            }
+        }
+    }
+    for (size_t t = 0; t < T; ++t)
+        if (!seen[t]) { err = "triangle " + std::to_string(t) + " is in no leaf"; return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+} // namespace rt

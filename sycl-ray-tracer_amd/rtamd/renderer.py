@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's renderer plugin surface over the C ABI.
+
+    IRenderer.render_frame(camera, scene)            src/render.hpp:11-18
+    MegakernelRenderer(img_size, max_depth, spp)     src/render_megakernel.hpp:13-19
+    WavefrontRenderer(img_size, max_depth, spp)      src/render_wavefront.hpp:55-61
+    Camera(img_size, center, dir, focal_length)      src/camera.hpp:74-106
+
+All rendering happens in librt_mi355x.so (HIP, gfx950). There is no CPU path here: constructing a
+Scene or renderer without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi
+from .scenes import SceneDesc
+
+
+class Camera:
+    """== raytracer::Camera; the constructor arithmetic runs in rt_camera_init (host C++)."""
+
+    def __init__(self, img_size, center, direction, focal_length: float):
+        self.c = abi.rt_camera()
+        lib = abi.load_library()
+        ce = (C.c_float * 3)(*[float(v) for v in center])
+        di = (C.c_float * 3)(*[float(v) for v in direction])
+        abi.check(lib.rt_camera_init(C.byref(self.c), int(img_size[0]), int(img_size[1]), ce, di, float(focal_length)))
+
+    @classmethod
+    def for_scene(cls, desc: SceneDesc, img_size):
+        p = desc.camera
+        return cls(img_size, p.position, p.direction, p.focal_length)
+
+
+class Scene:
+    """Device-resident scene: == what raytracer::Scene hands the kernels (RTCScene + GeometryData)."""
+
+    def __init__(self, desc: SceneDesc, device: int = 0, bvh: int = abi.RT_BVH_DEFAULT):
+        self.desc = desc
+        self.device = device
+        self._lib = abi.load_library()
+        self._c = desc.to_c()
+        self.h = C.c_void_p()
+        abi.check(self._lib.rt_scene_create(C.byref(self._c), device, bvh, C.byref(self.h)))
+
+    def info(self) -> abi.rt_scene_info_t:
+        out = abi.rt_scene_info_t()
+        abi.check(self._lib.rt_scene_info(self.h, C.byref(out)))
+        return out
+
+    def check_bvh(self) -> None:
+        abi.check(self._lib.rt_scene_check_bvh(self.h))
+
+    def intersect(self, org: np.ndarray, dirs: np.ndarray):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = org.shape[0]
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        tri = np.zeros(n, np.uint32)
+        abi.check(self._lib.rt_intersect_batch(self.h, n, abi.fptr(org), abi.fptr(dirs), abi.fptr(t), abi.fptr(u),
+                                               abi.fptr(v), abi.u32ptr(tri)))
+        return t, u, v, tri
+
+    def scatter(self, material: int, dirs, normals, uvs, seeds):
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        uvs = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        n = dirs.shape[0]
+        ok = np.zeros(n, np.uint8)
+        od, oa = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        so = np.zeros(n, np.uint32)
+        abi.check(self._lib.rt_probe_scatter(self.h, material, n, abi.fptr(dirs), abi.fptr(normals), abi.fptr(uvs),
+                                             abi.u32ptr(seeds), abi.u8ptr(ok), abi.fptr(od), abi.fptr(oa), abi.u32ptr(so)))
+        return ok, od, oa, so
+
+    def close(self):
+        if self.h:
+            self._lib.rt_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class Frame:
+    rgba_f32: np.ndarray | None  # (rows, W, 4) float32: sqrt(mean rgb), alpha 1 — pre-quantisation
+    rgba_u8: np.ndarray | None   # (rows, W, 4) uint8: the reference's RGBA-unorm8 image
+    rays: int
+    seconds: float
+    device_ms: float
+    hot_kernel_ms: float
+    hot_kernel_launches: int
+    launches: int
+
+    def stat_lines(self) -> list[str]:
+        """The three lines benchmark.py scrapes (src/render_wavefront.cpp:425-427, benchmark.py:49-55)."""
+        secs = self.device_ms * 1e-3
+        return [f"Time measured: {secs:.6f} seconds", f"Total rays: {self.rays}",
+                f"Rays/sec: {self.rays / secs / 1e6:.2f}M"]
+
+
+class IRenderer:
+    """== raytracer::IRenderer (src/render.hpp:11-18)."""
+    KIND = -1
+
+    def __init__(self, scene: Scene, img_size, max_depth: int = 10, sample_count: int = 32,
+                 seed_mode: int = abi.RT_SEED_DEFAULT):
+        self.scene = scene
+        self.img_size = (int(img_size[0]), int(img_size[1]))
+        self.max_depth, self.sample_count = int(max_depth), int(sample_count)
+        self._lib = abi.load_library()
+        self.h = C.c_void_p()
+        abi.check(self._lib.rt_renderer_create(self.KIND, scene.h, self.img_size[0], self.img_size[1], self.max_depth,
+                                               self.sample_count, seed_mode, C.byref(self.h)))
+
+    def set_tile(self, rank: int, world: int, strip_rows: int = 8) -> None:
+        abi.check(self._lib.rt_renderer_set_tile(self.h, rank, world, strip_rows))
+
+    def set_profiling(self, enable: bool) -> None:
+        abi.check(self._lib.rt_renderer_set_profiling(self.h, int(enable)))
+
+    @property
+    def local_rows(self) -> int:
+        return int(self._lib.rt_renderer_local_rows(self.h))
+
+    def global_rows(self) -> np.ndarray:
+        return np.array([self._lib.rt_renderer_global_row(self.h, i) for i in range(self.local_rows)], np.int64)
+
+    def render_frame(self, camera: Camera, scene: Scene | None = None, want_f32: bool = True, want_u8: bool = True) -> Frame:
+        if scene is not None and scene is not self.scene:
+            raise ValueError("renderer was created for a different scene")
+        rows, w = self.local_rows, self.img_size[0]
+        f = np.zeros((rows, w, 4), np.float32) if want_f32 else None
+        b = np.zeros((rows, w, 4), np.uint8) if want_u8 else None
+        st = abi.rt_stats()
+        abi.check(self._lib.rt_render_frame(self.h, C.byref(camera.c), abi.fptr(f) if want_f32 else None,
+                                            abi.u8ptr(b) if want_u8 else None, C.byref(st)))
+        return Frame(f, b, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches),
+                     int(st.launches))
+
+    def render_frame_device(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> Frame:
+        """Outputs go to DEVICE pointers (e.g. torch tensor .data_ptr()); nothing is copied to host."""
+        st = abi.rt_stats()
+        abi.check(self._lib.rt_render_frame_device(self.h, C.byref(camera.c), C.c_void_p(d_f32 or None),
+                                                   C.c_void_p(d_u8 or None), C.c_void_p(stream or None), C.byref(st)))
+        return Frame(None, None, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches),
+                     int(st.launches))
+
+    def close(self):
+        if self.h:
+            self._lib.rt_renderer_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MegakernelRenderer(IRenderer):
+    KIND = abi.RT_RENDERER_MEGAKERNEL
+
+
+class WavefrontRenderer(IRenderer):
+    KIND = abi.RT_RENDERER_WAVEFRONT
+
+
+def assemble_tiles(parts: list[np.ndarray], height: int, world: int, strip_rows: int = 8) -> np.ndarray:
+    """De-interleaves per-rank compact strip buffers (rank order) into the full frame."""
+    w, ch = parts[0].shape[1], parts[0].shape[2]
+    out = np.zeros((height, w, ch), parts[0].dtype)
+    for rank, p in enumerate(parts):
+        rows = [y for y in range(height) if (y // strip_rows) % world == rank]
+        out[rows] = p[: len(rows)]
+    return out

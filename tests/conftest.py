@@ -1,0 +1,44 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def rtlib():
+    """The product library. Built in-tree; tests never fall back to anything else."""
+    from rtamd import abi
+    if not abi.LIB_PATH.exists():
+        import __graft_entry__ as g
+        g.build()
+    return abi.load_library()
+
+
+@pytest.fixture(scope="session")
+def scene_cache():
+    from rtamd import scenes
+    cache = {}
+
+    def get(name, **kw):
+        key = (name, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = scenes.get_scene(name, **kw)
+        return cache[key]
+
+    return get

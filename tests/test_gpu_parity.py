@@ -1,0 +1,353 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI versus the CPU oracle
+on the same seeded inputs and versus the committed golden fixtures.
+
+The bar is BIT-EXACT equality of the fp32 framebuffer, the unorm8 image and the ray count (both sides
+execute the same IEEE operations in the same order: DESIGN.md §3), which trivially meets the north-star
+tolerance of per-pixel RMSE < 1e-4. Full-size frames, which the oracle cannot finish in seconds, are
+covered by size-independent properties plus oracle spot checks of sub-tiles."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rtamd import abi, scenes
+from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer, assemble_tiles
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+NO_TRI = 0xFFFFFFFF
+RMSE_TOL = 1e-4  # north-star tolerance; the tests below demand 0 and report the rmse on failure
+KINDS = [(MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL), (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT)]
+
+
+@pytest.fixture(scope="module")
+def gpu(rtlib):
+    n = rtlib.rt_device_count()
+    assert n > 0, "GPU tests need a device; the product has no CPU fallback"
+    return 0
+
+
+@pytest.fixture(scope="module")
+def gpu_scenes(gpu, scene_cache):
+    cache = {}
+
+    def get(name, bvh=abi.RT_BVH_DEFAULT, **kw):
+        key = (name, bvh, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = Scene(scene_cache(name, **kw), device=gpu, bvh=bvh)
+        return cache[key]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+def _assert_frames_equal(got_f, got_b, got_rays, exp_f, exp_b, exp_rays, what):
+    diff = got_f.astype(np.float64) - exp_f.astype(np.float64)
+    rmse = float(np.sqrt(np.mean(diff ** 2)))
+    nbad = int((got_f != exp_f).any(-1).sum())
+    assert got_rays == exp_rays, f"{what}: rays {got_rays} != {exp_rays} (rmse {rmse:.3e}, {nbad} px differ)"
+    assert nbad == 0, f"{what}: {nbad} pixels differ, rmse {rmse:.3e} (tolerance {RMSE_TOL})"
+    np.testing.assert_array_equal(got_b, exp_b)
+
+
+# ---- building blocks -----------------------------------------------------------------------------------
+def test_device_xorshift(rtlib, gpu, oracle):
+    for seed in (1, 0, 2463534242, 0xDEADBEEF):
+        out = np.zeros(256, np.float32)
+        st = C.c_uint32()
+        abi.check(rtlib.rt_probe_xorshift(gpu, seed, 256, abi.fptr(out), C.byref(st)))
+        exp, est = oracle.xorshift(seed, 256)
+        np.testing.assert_array_equal(out, exp)
+        assert st.value == est
+
+
+def test_device_half_roundtrip(rtlib, gpu, oracle):
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 2 ** 32, 300000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x = x[np.isfinite(x)]
+    x = np.concatenate([x, np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e-8, 2.9802322e-8, 3e-8, 6e-8, 6.1035156e-5,
+                                     1.00048828125, np.inf, -np.inf], np.float32),
+                        rng.uniform(-2, 2, 200000).astype(np.float32), (rng.uniform(-1, 1, 100000) * 1e-5).astype(np.float32)])
+    x = np.ascontiguousarray(x)
+    out = np.zeros_like(x)
+    bits = np.zeros(x.size, np.uint16)
+    abi.check(rtlib.rt_probe_half_roundtrip(gpu, x.size, abi.fptr(x), abi.fptr(out), bits.ctypes.data_as(C.POINTER(C.c_uint16))))
+    eo, eb = oracle.half_roundtrip(x)
+    np.testing.assert_array_equal(bits, eb)
+    np.testing.assert_array_equal(out, eo)
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_device_scatter_all_materials(gpu_scenes, oracle, scene_cache):
+    """Material::scatter on the device vs the oracle for random inputs, including back-face dielectric
+    hits (total internal reflection) and textured albedo lookups with wrapping uv."""
+    rng = np.random.default_rng(11)
+    for name, kw in (("cornell", {}), ("atrium", {"detail": 1})):
+        sd = scene_cache(name, **kw)
+        gs, osc = gpu_scenes(name, **kw), oracle.OracleScene(sd)
+        n = 20000
+        dirs = _unit(rng.normal(size=(n, 3)))
+        nrm = _unit(rng.normal(size=(n, 3)))
+        uv = rng.uniform(-3, 3, (n, 2)).astype(np.float32)
+        uv[:50] = np.array([[0.0, 0.0], [1.0, 1.0], [-1.0, 2.0], [0.999999, 0.5], [1e-9, -1e-9]] * 10, np.float32)
+        seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        seeds[:3] = (0, 1, 0xFFFFFFFF)
+        for m in range(len(sd.materials)):
+            g = gs.scatter(m, dirs, nrm, uv, seeds)
+            e = osc.scatter(m, dirs, nrm, uv, seeds)
+            np.testing.assert_array_equal(g[0], e[0], err_msg=f"{name} material {m}: ok flag")
+            np.testing.assert_array_equal(g[3], e[3], err_msg=f"{name} material {m}: rng state")
+            if sd.materials[m].type != abi.RT_MAT_NONE:
+                np.testing.assert_array_equal(g[1], e[1], err_msg=f"{name} material {m}: direction")
+                np.testing.assert_array_equal(g[2], e[2], err_msg=f"{name} material {m}: attenuation")
+
+
+@pytest.mark.parametrize("name,kw,brute", [("triangle", {}, True), ("cube", {}, True), ("cornell", {}, True),
+                                            ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False)])
+@pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH])
+def test_intersect_batch_equals_oracle(gpu_scenes, oracle, scene_cache, name, kw, brute, bvh):
+    """rtcIntersect1 replacement: BVH traversal on the GPU == brute force over all triangles on the CPU,
+    for camera rays, random interior rays and rays that start ON surfaces (the self-hit / tnear case)."""
+    sd = scene_cache(name, **kw)
+    gs, osc = gpu_scenes(name, bvh=bvh, **kw), oracle.OracleScene(sd)
+    rng = np.random.default_rng(5)
+    n = 6000 if brute and sd.n_triangles > 5000 else 20000
+    tw = sd.world_triangles()
+    lo, hi = tw.reshape(-1, 3).min(0), tw.reshape(-1, 3).max(0)
+    org = rng.uniform(lo - 0.1 * (hi - lo) - 0.5, hi + 0.1 * (hi - lo) + 0.5, (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs[: n // 4] *= 1e-2   # short unnormalised directions (scattered rays are unnormalised)
+    dirs = dirs.astype(np.float16).astype(np.float32)  # directions always pass through half storage
+    # rays that start on triangle surfaces
+    k = n // 3
+    ti = rng.integers(0, sd.n_triangles, k)
+    b = rng.dirichlet((1, 1, 1), k)
+    org[:k] = np.einsum("ij,ijk->ik", b, tw[ti]).astype(np.float32)
+    # axis-aligned directions with exact zeros (0 * inf in the slab test)
+    dirs[k: k + 60] = np.tile(np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 1, 1], [-1, 0, 1], [1, 1, 0]], np.float32), (10, 1))
+    gt, gu, gv, gtri = gs.intersect(org, dirs)
+    et, eu, ev, etri = osc.intersect(org, dirs, use_bvh=not brute)
+    assert (etri != NO_TRI).sum() > n // 10
+    np.testing.assert_array_equal(gtri, etri)
+    np.testing.assert_array_equal(gt, et)
+    np.testing.assert_array_equal(gu, eu)
+    np.testing.assert_array_equal(gv, ev)
+
+
+# ---- whole renders -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", sorted(p.stem for p in GOLDEN.glob("*.npz")))
+def test_render_equals_golden_fixtures(gpu_scenes, case):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", GOLDEN / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    scene, kw, w, h, spp, depth = mg.CASES[case]
+    g = np.load(GOLDEN / f"{case}.npz")
+    gs = gpu_scenes(scene, **kw)
+    cam = Camera.for_scene(gs.desc, (w, h))
+    for cls, tag in ((MegakernelRenderer, "mega"), (WavefrontRenderer, "wave")):
+        r = cls(gs, (w, h), depth, spp)
+        fr = r.render_frame(cam)
+        _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, g[f"{tag}_f32"], g[f"{tag}_u8"], int(g[f"{tag}_rays"]), f"{case}/{tag}")
+        r.close()
+    # primary-hit table through the intersect entry point
+    X, Y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="xy")
+    c = cam.c
+    p00, du, dv, ce = (np.array(list(v), np.float32) for v in (c.pixel00, c.delta_u, c.delta_v, c.center))
+    dirs = (((p00 + X[..., None] * du) + Y[..., None] * dv) - ce).astype(np.float32).reshape(-1, 3)
+    t, u, v, tri = gs.intersect(np.broadcast_to(ce, dirs.shape).copy(), dirs)
+    np.testing.assert_array_equal(tri, g["hit_tri"])
+    np.testing.assert_array_equal(t, g["hit_t"])
+    np.testing.assert_array_equal(u, g["hit_u"])
+    np.testing.assert_array_equal(v, g["hit_v"])
+
+
+# BASELINE.json configs, at sizes the oracle finishes in seconds (full sizes: properties test below)
+CONFIGS = [
+    ("triangle", {}, 256, 256, 1, 10, False),     # config 1 at full size
+    ("cube", {}, 256, 256, 4, 10, False),         # config 2 (512x512x16 at reduced size)
+    ("cornell", {}, 160, 160, 8, 10, False),      # config 3 (emissive -> wavefront clamp differs)
+    ("atrium", {"detail": 2}, 240, 136, 2, 10, True),  # configs 4/5 geometry class, oracle BVH
+    ("cornell", {}, 97, 61, 3, 1, False),         # odd size (partial 8x8 tiles), depth 1
+    ("cube", {}, 64, 40, 2, 16, False),           # depth 16 as in config 5
+]
+
+
+@pytest.mark.parametrize("name,kw,w,h,spp,depth,use_bvh", CONFIGS)
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_render_equals_oracle(gpu_scenes, oracle, scene_cache, cls, kind, name, kw, w, h, spp, depth, use_bvh):
+    sd = scene_cache(name, **kw)
+    gs = gpu_scenes(name, **kw)
+    r = cls(gs, (w, h), depth, spp)
+    fr = r.render_frame(Camera.for_scene(sd, (w, h)))
+    r.close()
+    osc = oracle.OracleScene(sd)
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    f, b, rays = osc.render(ocam, kind, depth, spp, use_bvh=use_bvh)
+    _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, f, b, rays, f"{name} {w}x{h} {spp}spp d{depth} {cls.__name__}")
+
+
+@pytest.mark.parametrize("seed_mode", [abi.RT_SEED_WAVEFRONT, abi.RT_SEED_MEGAKERNEL])
+def test_megakernel_equals_wavefront_with_equal_seeds(gpu_scenes, seed_mode):
+    """Appendix A-E3 on the device: equal seeds, no sample above 1 -> identical frames and ray counts."""
+    for name in ("triangle", "cube"):
+        gs = gpu_scenes(name)
+        w, h = 200, 120
+        cam = Camera.for_scene(gs.desc, (w, h))
+        a = MegakernelRenderer(gs, (w, h), 10, 6, seed_mode)
+        b = WavefrontRenderer(gs, (w, h), 10, 6, seed_mode)
+        fa, fb = a.render_frame(cam), b.render_frame(cam)
+        assert fa.rays == fb.rays
+        np.testing.assert_array_equal(fa.rgba_f32, fb.rgba_f32)
+        np.testing.assert_array_equal(fa.rgba_u8, fb.rgba_u8)
+        a.close(), b.close()
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_bvh_builder_does_not_change_the_image(gpu_scenes, cls, kind):
+    frames = []
+    for bvh in (abi.RT_BVH_LBVH, abi.RT_BVH_SAH):
+        gs = gpu_scenes("atrium", bvh=bvh, detail=2)
+        r = cls(gs, (320, 180), 10, 3)
+        frames.append(r.render_frame(Camera.for_scene(gs.desc, (320, 180))))
+        r.close()
+    assert frames[0].rays == frames[1].rays
+    np.testing.assert_array_equal(frames[0].rgba_f32, frames[1].rgba_f32)
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+@pytest.mark.parametrize("world,strip", [(2, 8), (3, 8), (8, 8), (4, 16)])
+def test_tile_split_union_equals_full_frame(gpu_scenes, cls, kind, world, strip):
+    """Multi-GPU tile split, all ranks rendered on this one GPU: the de-interleaved union of the tiles is
+    bit-identical to the single-GPU frame and the ray counts add up (seeds use global pixel coordinates)."""
+    gs = gpu_scenes("cornell")
+    w, h = 120, 93  # not a multiple of the strip height
+    cam = Camera.for_scene(gs.desc, (w, h))
+    r = cls(gs, (w, h), 10, 3)
+    full = r.render_frame(cam)
+    parts, rays = [], 0
+    for rank in range(world):
+        r.set_tile(rank, world, strip)
+        rows = r.global_rows()
+        assert all((y // strip) % world == rank for y in rows) and len(rows) == r.local_rows
+        fr = r.render_frame(cam)
+        parts.append(fr.rgba_f32)
+        rays += fr.rays
+    r.close()
+    assert rays == full.rays
+    np.testing.assert_array_equal(assemble_tiles(parts, h, world, strip), full.rgba_f32)
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_render_is_deterministic_and_reusable(gpu_scenes, cls, kind):
+    gs = gpu_scenes("atrium", detail=1)
+    w, h = 256, 144
+    cam = Camera.for_scene(gs.desc, (w, h))
+    r = cls(gs, (w, h), 10, 4)
+    a, b = r.render_frame(cam), r.render_frame(cam)  # same renderer twice: state is re-initialised per frame
+    assert a.rays == b.rays and a.rays > w * h * 4
+    np.testing.assert_array_equal(a.rgba_f32, b.rgba_f32)
+    np.testing.assert_array_equal(a.rgba_u8, np.clip(np.rint(np.clip(a.rgba_f32, 0, 1) * 255), 0, 255).astype(np.uint8))
+    r.close()
+
+
+def test_device_output_pointers(gpu_scenes):
+    """rt_render_frame_device writes into caller-owned device memory (torch tensors as plain pointers)."""
+    torch = pytest.importorskip("torch")
+    gs = gpu_scenes("cube")
+    w, h = 128, 72
+    cam = Camera.for_scene(gs.desc, (w, h))
+    r = WavefrontRenderer(gs, (w, h), 10, 2)
+    host = r.render_frame(cam)
+    f = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    b = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    fr = r.render_frame_device(cam, f.data_ptr(), b.data_ptr())
+    torch.cuda.synchronize()
+    assert fr.rays == host.rays
+    np.testing.assert_array_equal(f.cpu().numpy(), host.rgba_f32)
+    np.testing.assert_array_equal(b.cpu().numpy(), host.rgba_u8)
+    r.close()
+
+
+def test_edge_cases(gpu_scenes, oracle, scene_cache):
+    # empty scene: every ray misses -> sky; max_depth 0: no rays at all, black frame
+    gs = gpu_scenes("empty")
+    cam = Camera((40, 24), (0, 0, 0), (0, 0, -1), 1.0)
+    for cls, kind in KINDS:
+        r = cls(gs, (40, 24), 10, 3)
+        fr = r.render_frame(cam)
+        assert fr.rays == 40 * 24 * 3
+        f, b, rays = oracle.OracleScene(scene_cache("empty")).render(oracle.camera(40, 24, (0, 0, 0), (0, 0, -1), 1.0), kind, 10, 3)
+        np.testing.assert_array_equal(fr.rgba_f32, f)
+        r.close()
+        r0 = cls(gpu_scenes("cube"), (40, 24), 0, 2)
+        fr0 = r0.render_frame(Camera.for_scene(scene_cache("cube"), (40, 24)))
+        assert fr0.rays == 0 and not fr0.rgba_f32[..., :3].any()
+        r0.close()
+    # 1x1 image and a size below one tile
+    for (w, h) in ((1, 1), (3, 5)):
+        gs = gpu_scenes("cube")
+        sd = scene_cache("cube")
+        for cls, kind in KINDS:
+            r = cls(gs, (w, h), 5, 2)
+            fr = r.render_frame(Camera.for_scene(sd, (w, h)))
+            f, b, rays = oracle.OracleScene(sd).render(
+                oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length), kind, 5, 2)
+            _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, f, b, rays, f"{w}x{h}")
+            r.close()
+    # argument errors come back as codes, not crashes
+    lib = abi.load_library()
+    h_ = C.c_void_p()
+    assert lib.rt_renderer_create(7, gpu_scenes("cube").h, 8, 8, 1, 1, 0, C.byref(h_)) == abi.RT_ERR_INVALID
+    assert lib.rt_renderer_create(0, gpu_scenes("cube").h, 8, 8, 1, 0, 0, C.byref(h_)) == abi.RT_ERR_INVALID
+    r = WavefrontRenderer(gpu_scenes("cube"), (8, 8), 1, 1)
+    with pytest.raises(abi.RtError):
+        r.render_frame(Camera((9, 8), (0, 0, 0), (0, 0, -1), 1.0))
+    with pytest.raises(abi.RtError):
+        r.set_tile(2, 2)
+    r.close()
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_full_size_properties(gpu_scenes, oracle, scene_cache, cls, kind):
+    """BASELINE config 4 at full resolution (1920x1080, reduced spp so the test stays short): checked
+    through size-independent properties — (a) rows sampled across the frame equal the oracle's rows,
+    rendered as 1-row... tiles of the same frame, (b) rays/path within [1, depth], (c) unorm8 == quantised
+    fp32, (d) an 8-way tile split reassembles to the same frame."""
+    sd = scene_cache("atrium", detail=4)
+    gs = gpu_scenes("atrium", detail=4)
+    w, h, spp, depth = 1920, 1080, 2, 10
+    cam = Camera.for_scene(sd, (w, h))
+    r = cls(gs, (w, h), depth, spp)
+    full = r.render_frame(cam)
+    assert w * h * spp <= full.rays <= w * h * spp * depth
+    assert 4.0 < full.rays / (w * h * spp) < 10.0  # enclosed scene: long paths (Sponza ~9.2)
+    np.testing.assert_array_equal(full.rgba_u8[..., :3],
+                                  np.rint(np.clip(full.rgba_f32[..., :3], 0, 1) * 255).astype(np.uint8))
+    assert np.isfinite(full.rgba_f32).all() and (full.rgba_f32[..., 3] == 1).all()
+    # (d) tile split
+    parts, rays = [], 0
+    for rank in range(8):
+        r.set_tile(rank, 8, 8)
+        fr = r.render_frame(cam)
+        parts.append(fr.rgba_f32)
+        rays += fr.rays
+    r.close()
+    assert rays == full.rays
+    np.testing.assert_array_equal(assemble_tiles(parts, h, 8, 8), full.rgba_f32)
+    # (a) oracle spot check: strips 5, 60 and 130 of the frame (8 rows each) via the oracle's tile split
+    osc = oracle.OracleScene(sd)
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    n_strips = (h + 7) // 8
+    for strip in (5, 60, 130):
+        f, b, _ = osc.render(ocam, kind, depth, spp, use_bvh=True, rank=strip, world=n_strips, strip_rows=8)
+        got = full.rgba_f32[strip * 8: strip * 8 + 8]
+        nbad = int((got != f).any(-1).sum())
+        rmse = float(np.sqrt(np.mean((got.astype(np.float64) - f) ** 2)))
+        assert nbad == 0, f"strip {strip}: {nbad} pixels differ from the oracle (rmse {rmse:.3e})"

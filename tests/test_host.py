@@ -1,0 +1,188 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol,
+host-only scene/BVH building, argument validation, the camera constructor. No compute call needs a GPU
+here; GPU entry points must FAIL LOUDLY (no CPU fallback) when no device is present."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rtamd import abi, scenes
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _declared_functions():
+    text = (REPO / "include" / "rt_mi355x.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(rtlib):
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(rtlib, n), f"librt_mi355x.so does not export {n}"
+        assert n in abi.PROTOTYPES, f"{n} has no ctypes prototype in rtamd/abi.py"
+    assert rtlib.rt_abi_version() == 1
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors vs the real header, measured by compiling a C program against include/rt_mi355x.h."""
+    import subprocess
+    names = ["rt_camera", "rt_material", "rt_instance", "rt_scene_desc", "rt_scene_info_t", "rt_stats"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "rt_mi355x.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    for n, sz in zip(names, sizes):
+        assert C.sizeof(getattr(abi, n)) == sz, n
+    assert sizes[:3] == [56, 44, 104]
+
+
+def _host_scene(rtlib, sd, bvh=abi.RT_BVH_DEFAULT):
+    c = sd.to_c()
+    h = C.c_void_p()
+    rc = rtlib.rt_scene_create(C.byref(c), -1, bvh, C.byref(h))
+    assert rc == abi.RT_OK, rtlib.rt_last_error()
+    return h, c
+
+
+@pytest.mark.parametrize("name,kw", [("triangle", {}), ("cube", {}), ("cornell", {}), ("atrium", {"detail": 1}),
+                                      ("atrium", {"detail": 2}), ("empty", {})])
+@pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH])
+def test_host_bvh_is_structurally_valid(rtlib, scene_cache, name, kw, bvh):
+    sd = scene_cache(name, **kw)
+    h, _c = _host_scene(rtlib, sd, bvh)
+    try:
+        assert rtlib.rt_scene_check_bvh(h) == abi.RT_OK, rtlib.rt_last_error()
+        info = abi.rt_scene_info_t()
+        assert rtlib.rt_scene_info(h, C.byref(info)) == abi.RT_OK
+        assert info.n_triangles == sd.n_triangles
+        assert info.max_leaf_tris <= 4 and info.max_depth < 63
+        if sd.n_triangles:
+            tw = sd.world_triangles().reshape(-1, 3)
+            np.testing.assert_allclose(np.array(info.bounds_lo), tw.min(0), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(np.array(info.bounds_hi), tw.max(0), rtol=1e-6, atol=1e-6)
+    finally:
+        rtlib.rt_scene_destroy(h)
+
+
+def test_sah_tree_is_cheaper_than_lbvh(rtlib, scene_cache):
+    sd = scene_cache("atrium", detail=2)
+    costs = {}
+    for bvh in (abi.RT_BVH_LBVH, abi.RT_BVH_SAH):
+        h, _c = _host_scene(rtlib, sd, bvh)
+        info = abi.rt_scene_info_t()
+        rtlib.rt_scene_info(h, C.byref(info))
+        costs[bvh] = info.sah_cost
+        rtlib.rt_scene_destroy(h)
+    assert costs[abi.RT_BVH_SAH] < costs[abi.RT_BVH_LBVH]
+
+
+def test_scene_validation_errors(rtlib, scene_cache):
+    import copy
+    sd = copy.deepcopy(scene_cache("cube"))
+    h = C.c_void_p()
+    assert rtlib.rt_scene_create(None, -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
+    bad = copy.deepcopy(sd)
+    bad.indices = bad.indices.copy()
+    bad.indices[0, 0] = 10_000
+    c = bad.to_c()
+    assert rtlib.rt_scene_create(C.byref(c), -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
+    assert b"index" in rtlib.rt_last_error()
+    bad = copy.deepcopy(sd)
+    bad.tri_instance = bad.tri_instance.copy()
+    bad.tri_instance[3] = 7
+    c = bad.to_c()
+    assert rtlib.rt_scene_create(C.byref(c), -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
+    bad = copy.deepcopy(sd)
+    bad.inst_material = np.array([5], np.uint32)
+    c = bad.to_c()
+    assert rtlib.rt_scene_create(C.byref(c), -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
+    bad = copy.deepcopy(sd)
+    bad.positions = bad.positions.copy()
+    bad.positions[0, 0] = np.nan
+    c = bad.to_c()
+    assert rtlib.rt_scene_create(C.byref(c), -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
+    c = sd.to_c()
+    assert rtlib.rt_scene_create(C.byref(c), -1, 99, C.byref(h)) == abi.RT_ERR_INVALID
+
+
+def test_camera_init_equals_oracle_bitwise(rtlib, oracle):
+    for (w, h, pos, d, focal) in [(1920, 1080, (1.0, 2.0, 3.0), (0.3, -0.2, -1.0), 1.7),
+                                  (256, 256, (-3.9, 0.244, 0.218), (1.0, 0.0, 0.0), 1.0),
+                                  (1024, 1024, (0.0, 0.0, 3.9), (0.0, 0.0, -1.0), 2.7778263),
+                                  (3840, 2160, (-12.5, 2.2, 0.4), (1.0, 0.08, -0.03), 1.9445)]:
+        a = abi.rt_camera()
+        ce = (C.c_float * 3)(*pos)
+        di = (C.c_float * 3)(*d)
+        assert rtlib.rt_camera_init(C.byref(a), w, h, ce, di, focal) == abi.RT_OK
+        b = oracle.camera(w, h, pos, d, focal)
+        assert bytes(a) == bytes(b)
+    assert rtlib.rt_camera_init(None, 4, 4, ce, di, 1.0) == abi.RT_ERR_INVALID
+    assert rtlib.rt_camera_init(C.byref(a), 0, 4, ce, di, 1.0) == abi.RT_ERR_INVALID
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(rtlib, scene_cache):
+    """No CPU fallback: on a box without a GPU every compute entry point returns an error code."""
+    if rtlib.rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    sd = scene_cache("cube")
+    c = sd.to_c()
+    h = C.c_void_p()
+    assert rtlib.rt_scene_create(C.byref(c), 0, 0, C.byref(h)) == abi.RT_ERR_NO_DEVICE
+    assert b"no CPU fallback" in rtlib.rt_last_error()
+    hs, _c = _host_scene(rtlib, sd)
+    r = C.c_void_p()
+    assert rtlib.rt_renderer_create(0, hs, 64, 64, 10, 1, 0, C.byref(r)) == abi.RT_ERR_NO_DEVICE
+    t = np.zeros(1, np.float32)
+    tri = np.zeros(1, np.uint32)
+    o = np.zeros(3, np.float32)
+    assert rtlib.rt_intersect_batch(hs, 1, abi.fptr(o), abi.fptr(o), abi.fptr(t), abi.fptr(t), abi.fptr(t),
+                                    abi.u32ptr(tri)) == abi.RT_ERR_NO_DEVICE
+    out = np.zeros(4, np.float32)
+    st = C.c_uint32()
+    assert rtlib.rt_probe_xorshift(0, 1, 4, abi.fptr(out), C.byref(st)) == abi.RT_ERR_NO_DEVICE
+    rtlib.rt_scene_destroy(hs)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The product path may not import, call or link anything under oracle/."""
+    pkg = REPO / "sycl-ray-tracer_amd"
+    for p in pkg.rglob("*"):
+        if p.suffix in {".py", ".cpp", ".h", ".hip", ".hpp"} or p.name == "Makefile":
+            text = p.read_text(errors="ignore")
+            assert "oracle" not in text.lower().replace("cpu oracle", "").replace("the oracle", ""), f"{p} mentions oracle/"
+
+
+def test_glb_assets_decode_as_documented(scene_cache):
+    tri = scene_cache("triangle")
+    assert tri.n_triangles == 1 and tri.materials[0].type == abi.RT_MAT_DIFFUSE
+    np.testing.assert_allclose(tri.materials[0].color, (0.8, 0.8, 0.8), atol=1e-7)
+    np.testing.assert_allclose(tri.positions[:, 0], -0.8968592, atol=1e-6)
+    np.testing.assert_array_equal(tri.indices[0], [1, 2, 0])
+    cube = scene_cache("cube")
+    assert cube.n_triangles == 12 and cube.positions.shape == (24, 3)
+    # no material in the file -> glTF defaults -> metallic (factor 1 > 0.01), roughness 1, white
+    m = cube.materials[0]
+    assert m.type == abi.RT_MAT_METALLIC and m.roughness == 1.0 and tuple(m.color) == (1.0, 1.0, 1.0)
+    np.testing.assert_allclose(cube.transforms[0][12:15], (0.05813105, 0.1505536, -2.9208844), atol=1e-6)
+
+
+def test_normal_matrix_is_inverse_transpose():
+    m = scenes.trs((1, 2, 3), scenes.quat_axis_angle((0.3, 1, 0.2), 0.7), (0.5, 2.0, 1.5))
+    nm = scenes.normal_matrix(m).reshape(3, 3).T.astype(np.float64)  # to row-major
+    m3 = m.reshape(4, 4).T[:3, :3].astype(np.float64)
+    np.testing.assert_allclose(nm, np.linalg.inv(m3).T, atol=1e-6)
+
+
+def test_atrium_generator_is_deterministic():
+    a, b = scenes.atrium_scene(1), scenes.atrium_scene(1)
+    for k in ("positions", "normals", "uvs", "indices", "tri_instance", "transforms", "normal_mats", "textures"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    assert 10_000 < a.n_triangles < 30_000
+    assert a.textures.shape[0] == 9
