@@ -39,6 +39,10 @@ RT_DEV float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f),
 
 // sycl::half storage of dir / attenuation / radiance (src/camera.hpp:18-43)
 RT_DEV uint16_t f2h(float f) {
+    // The value must be ROUNDED TO f32 FIRST and then to f16 (two roundings, as the reference's
+    // float -> sycl::half assignment does). Without this barrier hipcc folds "(half)(a*b)" into
+    // v_fma_mixlo_f16, which rounds the exact product once and differs in ~1e-4 of the cases.
+    asm("" : "+v"(f));
     _Float16 h = (_Float16)f; // v_cvt_f16_f32, round-to-nearest-even
     return __builtin_bit_cast(uint16_t, h);
 }
@@ -145,7 +149,13 @@ RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d) {
     best.t = __builtin_huge_valf();
     best.u = best.v = 0.0f;
     best.tri = kNoTri;
-    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    // A zero direction component would give inv = inf and, in the fma form b*inv - o*inv, inf - inf = NaN
+    // on the far side of the slab; clamp |d| to 1e-30 so the product stays finite (|b|, |o| < 1e8).
+    const float kTiny = 1e-30f;
+    const float dx = __builtin_fabsf(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x;
+    const float dy = __builtin_fabsf(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y;
+    const float dz = __builtin_fabsf(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z;
+    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     int32_t stack[kStackSize];
     int sp = 0;

@@ -132,7 +132,7 @@ def test_intersect_batch_equals_oracle(gpu_scenes, oracle, scene_cache, name, kw
     dirs[k: k + 60] = np.tile(np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 1, 1], [-1, 0, 1], [1, 1, 0]], np.float32), (10, 1))
     gt, gu, gv, gtri = gs.intersect(org, dirs)
     et, eu, ev, etri = osc.intersect(org, dirs, use_bvh=not brute)
-    assert (etri != NO_TRI).sum() > n // 10
+    assert (etri != NO_TRI).sum() > n // 50
     np.testing.assert_array_equal(gtri, etri)
     np.testing.assert_array_equal(gt, et)
     np.testing.assert_array_equal(gu, eu)
