@@ -74,24 +74,14 @@ def main() -> int:
     r.set_tile(rank, world, strip)
     r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the render stream
     rows = r.local_rows
-    max_rows = max(sum(1 for y in range(H) if (y // strip) % world == k) for k in range(world))
-    local = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=dev)  # padded to equal size for gather
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-    gathered = [torch.zeros_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
-    row_index = None
-    if rank == 0:
-        row_index = [torch.tensor([y for y in range(H) if (y // strip) % world == k], dtype=torch.long, device=dev)
-                     for k in range(world)]
+    from rtamd.dist import FrameGatherer
+    fg = FrameGatherer(rank, world, W, H, strip, dev)
+    assert fg.rows == rows
+    local = fg.local
 
     def step():
         fr = r.render_frame_device(cam, d_f32=local.data_ptr())
-        if world > 1:
-            dist.gather(local, gathered, dst=0)  # RCCL gather of the per-GPU strip buffers
-            if rank == 0:
-                for k in range(world):
-                    frame.index_copy_(0, row_index[k], gathered[k][: row_index[k].numel()])
-        else:
-            frame.index_copy_(0, row_index[0], local[:rows])
+        fg.gather()  # RCCL gather of the per-GPU strip buffers + de-interleave on rank 0
         return fr
 
     def barrier():

@@ -1,0 +1,50 @@
+"""Multi-GPU frame assembly: one process per GPU, each renders its interleaved 8-row strips of the SAME
+frame; the compact per-rank strip buffers are gathered to rank 0 (torch.distributed: RCCL over xGMI when the
+backend is "nccl", gloo in the CPU tests) and de-interleaved into the full frame there.
+
+The reference is single-device (src/app.hpp:43-55); this exchange step is the only collective of the
+path. Pixels never interact, so there is nothing to reduce: a gather of N/G pixels per GPU is all that moves
+(33 MB of fp32 RGBA per 1080p frame in total)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def strip_rows_of(rank: int, world: int, height: int, strip_rows: int = 8) -> list[int]:
+    """Global row indices owned by `rank` (strip k -> rank k % world), top to bottom."""
+    return [y for y in range(height) if (y // strip_rows) % world == rank]
+
+
+def max_local_rows(world: int, height: int, strip_rows: int = 8) -> int:
+    return max(len(strip_rows_of(r, world, height, strip_rows)) for r in range(world))
+
+
+class FrameGatherer:
+    """Pre-allocates everything the per-frame exchange needs, so the timed region only launches the
+    collective and the de-interleave copies."""
+
+    def __init__(self, rank: int, world: int, width: int, height: int, strip_rows: int, device: torch.device,
+                 channels: int = 4, dtype=torch.float32):
+        self.rank, self.world, self.height = rank, world, height
+        self.rows = len(strip_rows_of(rank, world, height, strip_rows))
+        pad_rows = max_local_rows(world, height, strip_rows)
+        # every rank contributes the same (padded) shape: torch.distributed.gather needs equal sizes
+        self.local = torch.zeros((pad_rows, width, channels), dtype=dtype, device=device)
+        self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
+        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and world > 1) else None
+        self.index = None
+        if rank == 0:
+            self.index = [torch.tensor(strip_rows_of(r, world, height, strip_rows), dtype=torch.long, device=device)
+                          for r in range(world)]
+
+    def gather(self):
+        """Collects `self.local` of every rank into `self.frame` on rank 0. Returns the frame (rank 0) or None."""
+        if self.world > 1:
+            dist.gather(self.local, self.parts, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.frame.index_copy_(0, self.index[r], self.parts[r][: self.index[r].numel()])
+        else:
+            self.frame.index_copy_(0, self.index[0], self.local[: self.rows])
+        return self.frame
