@@ -40,14 +40,16 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     return __float_as_uint(o.w);
 }
 
-// one bounce on a RayState: unpack halves -> trace_ray -> repack (the body of render_pixel's loop,
-// src/render_megakernel.cpp:34-55, and of shoot_rays, src/render_wavefront.cpp:245-291)
-RT_DEV bool bounce(const SceneDev& S, uint32_t& rng, RayState& r, f3& result) {
+RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
+
+// the part of one bounce after the closest-hit query: unpack halves -> shade_hit -> repack (the body of
+// render_pixel's loop, src/render_megakernel.cpp:34-55, and of shoot_rays, src/render_wavefront.cpp:245-291)
+RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result) {
     f3 org = r.org;
-    f3 dir = mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2]));
+    f3 dir = ray_dir(r);
     f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
     f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-    const bool done = trace_ray(S, rng, org, dir, att, rad, result);
+    const bool done = shade_hit(S, rng, h, org, dir, att, rad, result);
     r.org = org;
     r.dir[0] = f2h(dir.x), r.dir[1] = f2h(dir.y), r.dir[2] = f2h(dir.z);
     r.att[0] = f2h(att.x), r.att[1] = f2h(att.y), r.att[2] = f2h(att.z);
@@ -62,9 +64,14 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ---- K1: megakernel ---------------------------------------------------------------------------------
-// One lane per pixel; a 64-thread block is one wave covering an 8x8 pixel tile. The sample and
-// depth loops of render_pixel are flattened into ONE loop so a lane whose path ended starts its
-// next sample at once instead of idling until the wave's longest path finishes.
+// One lane per pixel; a 64-thread block is one wave covering an 8x8 pixel tile. The sample loop, the
+// depth loop and the BVH traversal of render_pixel are flattened into ONE wave-level state machine:
+//   TRAVERSE  all lanes with a ray in flight take uniform traversal steps (trav_step_wave) until at
+//             least half of the lanes that still have work are waiting for shading;
+//   SHADE     the waiting lanes shade their hit, scatter, and either continue the path, start the next
+//             sample (new camera ray) or retire the pixel.
+// A lane therefore never idles while another lane finishes a long traversal or a long path; per-pixel
+// arithmetic and its order are unchanged (bit-exact with the per-pixel loops of the reference).
 __global__ void __launch_bounds__(64) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
@@ -76,28 +83,49 @@ __global__ void __launch_bounds__(64) k_megakernel(SceneDev S, CameraDev cam, Ti
     const int ly = ty * 8 + (lane >> 3); // local row
     const int gy = tile_global_row(tile, ly);
     const bool active = x < cam.width && ly < tile.local_rows && gy < cam.height;
-    uint32_t rays = 0;
+    uint32_t rays = 0, rng = 0, s = 0, depth = 0;
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    RayState r{};
+    Trav T;
+    int32_t stack[kStackSize];
+    T.cur = kTravDone;
+    bool live = false; // this lane still has samples to finish
     if (active) {
-        uint32_t rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
-        f3 color = mk3(0.0f, 0.0f, 0.0f);
+        rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
         if (max_depth == 0) {
-            for (uint32_t s = 0; s < spp; ++s) (void)camera_ray(cam, x, gy, rng);
+            for (uint32_t i = 0; i < spp; ++i) (void)camera_ray(cam, x, gy, rng);
         } else {
-            uint32_t s = 0, depth = 0;
-            RayState r = camera_ray(cam, x, gy, rng);
-            while (s < spp) {
-                f3 res;
-                rays++;
-                const bool done = bounce(S, rng, r, res);
-                depth++;
-                if (done || depth == max_depth) {
-                    if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
-                    s++;
-                    depth = 0;
-                    if (s < spp) r = camera_ray(cam, x, gy, rng);
-                }
-            }
+            live = true;
+            r = camera_ray(cam, x, gy, rng);
+            trav_begin(T, r.org, ray_dir(r));
         }
+    }
+    for (;;) {
+        // TRAVERSE until at most half of the live lanes are still traversing
+        const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+        if (n_live == 0) break;
+        for (;;) {
+            const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
+            if ((uint32_t)__popcll(__ballot(waiting)) * 2u >= n_live) break;
+            (void)trav_step_wave(S, T, stack);
+        }
+        // SHADE the lanes whose traversal is complete
+        if (live && T.cur == kTravDone) {
+            f3 res;
+            rays++;
+            const bool done = shade_bounce(S, rng, r, T.best, res);
+            depth++;
+            if (done || depth == max_depth) {
+                if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
+                s++;
+                depth = 0;
+                if (s < spp) r = camera_ray(cam, x, gy, rng);
+                else live = false;
+            }
+            if (live) trav_begin(T, r.org, ray_dir(r));
+        }
+    }
+    if (active) {
         const float n = (float)spp;
         const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
         const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
@@ -151,13 +179,21 @@ __global__ void __launch_bounds__(256) k_wf_shoot(SceneDev S, QueueDev qin, Queu
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x * 256u >= n) return; // whole block idle (uniform exit)
     bool survive = false;
-    RayState r;
+    RayState r{};
     uint32_t id = 0;
+    int32_t stack[kStackSize];
+    Trav T;
+    T.cur = kTravDone;
     if (i < n) {
         id = queue_load(qin, i, r);
+        trav_begin(T, r.org, ray_dir(r));
+    }
+    while (trav_step_wave(S, T, stack)) {}
+    if (i < n) {
+        const Hit hit = T.best;
         uint32_t st = rng[id]; // ScopedRng load (src/render_wavefront.cpp:15-32)
         f3 res;
-        const bool done = bounce(S, st, r, res);
+        const bool done = shade_bounce(S, st, r, hit, res);
         rng[id] = st;          // ScopedRng store
         if (done) {
             float4 acc = accum[id];
@@ -205,7 +241,8 @@ __global__ void __launch_bounds__(256) k_intersect_batch(SceneDev S, uint32_t n,
                                                           uint32_t* __restrict__ tri) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    int32_t stack[kStackSize];
+    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), stack);
     t[i] = h.t, u[i] = h.u, v[i] = h.v, tri[i] = h.tri;
 }
 
