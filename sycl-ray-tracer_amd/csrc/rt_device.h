@@ -142,7 +142,7 @@ RT_DEV void tri_test(const TriRec* __restrict__ tr, f3 o, f3 d, Hit& best) {
     }
 }
 
-// ---- BVH2 traversal as a resumable per-lane state machine --------------------------------------------
+// ---- BVH4 traversal as a resumable per-lane state machine --------------------------------------------
 // One ray per lane. A lane is in one of three states, encoded in `cur`:
 //   cur >= 0            at an inner node (index `cur`)
 //   cur <  0, != DONE   at a leaf: ~cur = (first << 2) | (remaining - 1), triangles tested ONE per step
@@ -183,37 +183,67 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d) {
 
 RT_DEV void trav_pop(Trav& T, const int32_t* stack) { T.cur = T.sp > 0 ? stack[--T.sp] : kTravDone; }
 
-// inner step: fetch the 64-byte node, test both child boxes, descend into the nearer hit child
+// byte k of a word as float (v_cvt_f32_ubyteK)
+RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
+RT_DEV float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
+RT_DEV float ub2(uint32_t w) { return (float)((w >> 16) & 0xffu); }
+RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
+
+// inner step: fetch the 64-byte BVH4 node, decode and test its four quantised child boxes, descend into
+// the nearest hit child and push the other hits far-to-near.
+//   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
+// The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
+// min/max pairing is needed.
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, int32_t* stack) {
-    const float4* np = reinterpret_cast<const float4*>(S.nodes + T.cur);
-    const float4 bx = np[0], by = np[1], bz = np[2];
-    const int2 ch = *reinterpret_cast<const int2*>(np + 3);
-    float x0 = __builtin_fmaf(bx.x, T.ix, T.ox), x1 = __builtin_fmaf(bx.y, T.ix, T.ox);
-    float y0 = __builtin_fmaf(by.x, T.iy, T.oy), y1 = __builtin_fmaf(by.y, T.iy, T.oy);
-    float z0 = __builtin_fmaf(bz.x, T.iz, T.oz), z1 = __builtin_fmaf(bz.y, T.iz, T.oz);
-    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
-                                      __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
-    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
-                                      __builtin_fminf(__builtin_fmaxf(z0, z1), T.best.t));
-    x0 = __builtin_fmaf(bx.z, T.ix, T.ox), x1 = __builtin_fmaf(bx.w, T.ix, T.ox);
-    y0 = __builtin_fmaf(by.z, T.iy, T.oy), y1 = __builtin_fmaf(by.w, T.iy, T.oy);
-    z0 = __builtin_fmaf(bz.z, T.iz, T.oz), z1 = __builtin_fmaf(bz.w, T.iz, T.oz);
-    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
-                                      __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
-    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
-                                      __builtin_fminf(__builtin_fmaxf(z0, z1), T.best.t));
-    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    if (h0 && h1) {
-        const bool swap = tn1 < tn0;
-        stack[T.sp++] = swap ? ch.x : ch.y; // far child waits
-        T.cur = swap ? ch.y : ch.x;
-    } else if (h0) {
-        T.cur = ch.x;
-    } else if (h1) {
-        T.cur = ch.y;
-    } else {
-        trav_pop(T, stack);
+    const uint4* np = reinterpret_cast<const uint4*>(S.nodes + T.cur);
+    const uint4 w0 = np[0], w1 = np[1];
+    const uint2 w2 = *reinterpret_cast<const uint2*>(np + 2);
+    const int4 ch = *reinterpret_cast<const int4*>(np + 3);
+    const float ax = __uint_as_float((w0.w & 0xffu) << 23) * T.ix;
+    const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * T.iy;
+    const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * T.iz;
+    const float bx = __builtin_fmaf(__uint_as_float(w0.x), T.ix, T.ox);
+    const float by = __builtin_fmaf(__uint_as_float(w0.y), T.iy, T.oy);
+    const float bz = __builtin_fmaf(__uint_as_float(w0.z), T.iz, T.oz);
+    const bool nx = T.ix < 0.0f, ny = T.iy < 0.0f, nz = T.iz < 0.0f;
+    const uint32_t qnx = nx ? w1.y : w1.x, qfx = nx ? w1.x : w1.y;
+    const uint32_t qny = ny ? w1.w : w1.z, qfy = ny ? w1.z : w1.w;
+    const uint32_t qnz = nz ? w2.y : w2.x, qfz = nz ? w2.x : w2.y;
+    const float inf = __builtin_huge_valf();
+    float k0, k1, k2, k3;
+#define RT_CHILD(K, CVT, CH)                                                                              \
+    {                                                                                                    \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
+                                         __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
+                                         __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
+        K = (tn <= tf && (CH) != kChildEmpty) ? tn : inf;                                                \
     }
+    RT_CHILD(k0, ub0, ch.x)
+    RT_CHILD(k1, ub1, ch.y)
+    RT_CHILD(k2, ub2, ch.z)
+    RT_CHILD(k3, ub3, ch.w)
+#undef RT_CHILD
+    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    // 5-comparator sorting network on (entry distance, child); misses carry +inf and sink to the end
+#define RT_CE(KA, CA, KB, CB)                                   \
+    {                                                          \
+        const bool sw = KB < KA;                               \
+        const float ka = sw ? KB : KA, kb = sw ? KA : KB;      \
+        const int32_t ca = sw ? CB : CA, cb = sw ? CA : CB;    \
+        KA = ka, KB = kb, CA = ca, CB = cb;                    \
+    }
+    RT_CE(k0, c0, k1, c1)
+    RT_CE(k2, c2, k3, c3)
+    RT_CE(k0, c0, k2, c2)
+    RT_CE(k1, c1, k3, c3)
+    RT_CE(k1, c1, k2, c2)
+#undef RT_CE
+    if (k3 < inf) stack[T.sp++] = c3; // farthest first
+    if (k2 < inf) stack[T.sp++] = c2;
+    if (k1 < inf) stack[T.sp++] = c1;
+    if (k0 < inf) T.cur = c0;
+    else trav_pop(T, stack);
 }
 
 // leaf step: test ONE triangle of the leaf, then move to the next one or pop

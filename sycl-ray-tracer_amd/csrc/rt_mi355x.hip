@@ -297,6 +297,8 @@ int rt_camera_init(rt_camera* out, int32_t width, int32_t height, const float ce
 int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "null output pointer");
     *out = nullptr;
+    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH)
+        return fail(RT_ERR_INVALID, "unknown bvh_kind");
     rt_scene* s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ERR_OOM, "host allocation failed");
     std::string err;

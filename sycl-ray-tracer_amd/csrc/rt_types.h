@@ -6,19 +6,26 @@
 namespace rt {
 
 // ---- BVH ----------------------------------------------------------------------------------------
-// 64-byte node holding the boxes of BOTH children, so one 4 x dwordx4 fetch decides a traversal
-// step. Bounds are interleaved per axis: bx = (lo0.x, hi0.x, lo1.x, hi1.x), by, bz likewise.
+// 4-wide BVH, 64-byte nodes, child boxes quantised to 8 bits per plane on a per-node grid:
+//     plane = origin[axis] + q * 2^(exp[axis] - 127)          (q = 0..255)
+// quantised conservatively (lo rounded down, hi rounded up) after padding, so a decoded box always
+// contains the padded exact box. One node = 4 x dwordx4 loads and decides FOUR children (the first
+// version, a BVH2 with fp32 boxes, needed the same 4 loads for two): half the L1 accesses per box
+// and half the dependent fetches per ray.
+//   word 0-2  origin.xyz (f32)      word 3     ex | ey << 8 | ez << 16 (biased f32 exponents)
+//   word 4-9  qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z : byte k belongs to child k
+//   word 10-11 unused               word 12-15 child[4]
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 2) | (count - 1), with
-// `first` indexing the leaf-ordered triangle array and 1 <= count <= 4. An absent child (scenes
-// with fewer than two leaves) has an inverted box (lo = +inf, hi = -inf) that no ray can enter.
+// `first` indexing the leaf-ordered triangle array and 1 <= count <= 4.  child == kChildEmpty: absent.
 struct alignas(64) BvhNode {
-    float bx[4];
-    float by[4];
-    float bz[4];
-    int32_t child[2];
+    float origin[3];
+    uint32_t exps;
+    uint32_t q[6]; // qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z
     uint32_t pad[2];
+    int32_t child[4];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+constexpr int32_t kChildEmpty = (int32_t)0x80000000;
 
 constexpr int kMaxLeafTris = 4;
 constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64

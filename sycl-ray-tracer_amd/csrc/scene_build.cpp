@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <functional>
 #include <queue>
 
 namespace rt {
@@ -145,7 +146,7 @@ void build_lbvh(Builder& b) {
 }
 
 // ---- binned SAH, top-down -------------------------------------------------------------------------
-void build_sah(Builder& b) {
+void build_sah(Builder& b, uint32_t max_sah_depth) {
     const uint32_t n = (uint32_t)b.order.size();
     constexpr int NB = 32;
     struct Work {
@@ -170,7 +171,7 @@ void build_sah(Builder& b) {
             const float parent_area = half_area(nd.lo, nd.hi);
             float best_cost = std::numeric_limits<float>::infinity();
             int best_axis = -1, best_bin = -1;
-            if (w.depth < 48) {
+            if (w.depth < max_sah_depth) {
                 for (int a = 0; a < 3; ++a) {
                     float ext = chi[a] - clo[a];
                     if (!(ext > 0.0f)) continue;
@@ -240,16 +241,58 @@ void build_sah(Builder& b) {
     }
 }
 
-inline void set_child_box(BvhNode& n, int c, const float* lo, const float* hi, float pad) {
-    n.bx[2 * c] = lo[0] - pad, n.bx[2 * c + 1] = hi[0] + pad;
-    n.by[2 * c] = lo[1] - pad, n.by[2 * c + 1] = hi[1] + pad;
-    n.bz[2 * c] = lo[2] - pad, n.bz[2 * c + 1] = hi[2] + pad;
+inline float grid_step(uint32_t biased_exp) { // 2^(e-127) as a float, exactly as the kernel decodes it
+    uint32_t bits = biased_exp << 23;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
 }
-inline void set_absent(BvhNode& n, int c) {
-    const float inf = std::numeric_limits<float>::infinity();
-    n.bx[2 * c] = n.by[2 * c] = n.bz[2 * c] = inf;
-    n.bx[2 * c + 1] = n.by[2 * c + 1] = n.bz[2 * c + 1] = -inf;
-    n.child[c] = ~0; // leaf(first 0, count 1); unreachable behind the inverted box
+
+// Quantises the (already padded) child boxes of one BVH4 node. Returns false only on non-finite input.
+bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)[3]) {
+    float nlo[3], nhi[3];
+    for (int a = 0; a < 3; ++a) {
+        nlo[a] = klo[0][a], nhi[a] = khi[0][a];
+        for (int k = 1; k < nk; ++k) nlo[a] = std::min(nlo[a], klo[k][a]), nhi[a] = std::max(nhi[a], khi[k][a]);
+        if (!std::isfinite(nlo[a]) || !std::isfinite(nhi[a])) return false;
+        n.origin[a] = nlo[a];
+    }
+    uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t exps = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = (double)nhi[a] - (double)nlo[a];
+        int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+        e = std::max(-100, std::min(100, e));
+        for (;; ++e) { // raise the grid step until every plane fits in 8 bits
+            const float s = grid_step((uint32_t)(e + 127));
+            uint32_t lo_b = 0, hi_b = 0;
+            bool ok = true;
+            for (int k = 0; k < 4 && ok; ++k) {
+                uint32_t ql = 255, qh = 0; // absent child: inverted (never decoded as a hit: child word says empty)
+                if (k < nk) {
+                    double fl = std::floor(((double)klo[k][a] - (double)nlo[a]) / (double)s);
+                    double fh = std::ceil(((double)khi[k][a] - (double)nlo[a]) / (double)s);
+                    long il = (long)std::max(0.0, std::min(255.0, fl)), ih = (long)std::max(0.0, std::min(256.0, fh));
+                    // verify with the kernel's own float decode; nudge outwards if rounding bit us
+                    while (il > 0 && n.origin[a] + (float)il * s > klo[k][a]) --il;
+                    while (ih <= 255 && n.origin[a] + (float)ih * s < khi[k][a]) ++ih;
+                    if (ih > 255 || n.origin[a] + (float)il * s > klo[k][a]) { ok = false; break; }
+                    ql = (uint32_t)il, qh = (uint32_t)ih;
+                }
+                lo_b |= ql << (8 * k), hi_b |= qh << (8 * k);
+            }
+            if (ok) {
+                q[2 * a] = lo_b, q[2 * a + 1] = hi_b;
+                exps |= (uint32_t)(e + 127) << (8 * a);
+                break;
+            }
+            if (e > 120) return false;
+        }
+    }
+    n.exps = exps;
+    for (int i = 0; i < 6; ++i) n.q[i] = q[i];
+    n.pad[0] = n.pad[1] = 0;
+    return true;
 }
 
 } // namespace
@@ -265,7 +308,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     if (d->n_layers > RT_TEX_MAX_LAYERS) { err = "more than 128 texture layers"; return RT_ERR_INVALID; }
     if (d->n_layers && !d->textures) { err = "null texture array"; return RT_ERR_INVALID; }
     if (d->n_triangles >= (1u << 28)) { err = "too many triangles (limit 2^28)"; return RT_ERR_INVALID; }
-    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH) {
+    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH && bvh_kind != RT_BVH_MEDIAN_INTERNAL) {
         err = "unknown bvh_kind"; return RT_ERR_INVALID;
     }
     for (uint32_t i = 0; i < d->n_instances; ++i) {
@@ -338,18 +381,23 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         if (!std::isfinite(hs.wverts[i])) { err = "non-finite world-space vertex"; return RT_ERR_INVALID; }
     }
 
-    BvhNode root{};
-    set_absent(root, 0), set_absent(root, 1);
-    root.pad[0] = root.pad[1] = 0;
+    auto empty_node = []() {
+        BvhNode n{};
+        n.exps = (127u) | (127u << 8) | (127u << 16);
+        for (int i = 0; i < 6; ++i) n.q[i] = (i & 1) ? 0u : 0xFFFFFFFFu; // qlo = 255, qhi = 0
+        for (int k = 0; k < 4; ++k) n.child[k] = kChildEmpty;
+        return n;
+    };
     if (T == 0) {
-        hs.nodes.assign(1, root);
+        hs.nodes.assign(1, empty_node());
         hs.tris.assign(1, TriRec{}); // one dummy record so device pointers are never null
         hs.tris[0].global_index = kNoTri;
         return RT_OK;
     }
 
     Builder b(hs.wverts);
-    if (bvh_kind == RT_BVH_LBVH) build_lbvh(b); else build_sah(b);
+    if (bvh_kind == RT_BVH_LBVH) build_lbvh(b);
+    else build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
 
     const GNode& g0 = b.nodes[0];
     for (int a = 0; a < 3; ++a) hs.bounds_lo[a] = g0.lo[a], hs.bounds_hi[a] = g0.hi[a];
@@ -363,56 +411,93 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     // would also miss ("culling is conservative").
     hs.pad = 2e-5f * std::max(ext, amax) + 1e-30f;
 
-    // emit in breadth-first order (top levels contiguous -> LDS staging of the first N nodes)
+    // Collapse the binary tree into a 4-wide one (repeatedly open the inner child with the largest
+    // surface area) and emit it breadth-first: the top levels are contiguous in memory.
     hs.tris.clear();
     hs.tris.reserve(T);
     hs.nodes.clear();
-    auto leaf_code = [&](const GNode& g) -> int32_t {
+    auto leaf_code = [&](const GNode& g, uint32_t depth) -> int32_t {
         uint32_t first = (uint32_t)hs.tris.size();
         for (uint32_t k = 0; k < g.count; ++k) hs.tris.push_back(gtris[b.order[g.first + k]]);
         hs.max_leaf_tris = std::max(hs.max_leaf_tris, g.count);
-        hs.max_depth = std::max(hs.max_depth, g.depth);
+        hs.max_depth = std::max(hs.max_depth, depth);
         return ~(int32_t)((first << 2) | (g.count - 1));
     };
     const double root_area = std::max(1e-30, (double)half_area(g0.lo, g0.hi));
     double cost = 0.0;
-    if (g0.left < 0) {
+    struct Item { int32_t gnode; int32_t slot; uint32_t depth; };
+    std::queue<Item> q;
+    hs.nodes.push_back(empty_node());
+    if (g0.left < 0) { // a single leaf: give the root one leaf child
         if (g0.count > (uint32_t)kMaxLeafTris) { err = "internal: oversized root leaf"; return RT_ERR_INVALID; }
-        set_child_box(root, 0, g0.lo, g0.hi, hs.pad);
-        root.child[0] = leaf_code(g0);
-        hs.nodes.push_back(root);
+        BvhNode root = empty_node();
+        float klo[1][3], khi[1][3];
+        for (int a = 0; a < 3; ++a) klo[0][a] = g0.lo[a] - hs.pad, khi[0][a] = g0.hi[a] + hs.pad;
+        if (!quantise_node(root, 1, klo, khi)) { err = "internal: quantisation failed"; return RT_ERR_INVALID; }
+        root.child[0] = leaf_code(g0, 1);
+        hs.nodes[0] = root;
         hs.sah_cost = (double)g0.count;
         return RT_OK;
     }
-    std::queue<std::pair<int32_t, int32_t>> q; // (generic node, output slot)
-    hs.nodes.push_back(BvhNode{});
-    q.push({0, 0});
+    q.push({0, 0, 0});
     while (!q.empty()) {
-        auto [gi, slot] = q.front();
+        const Item it = q.front();
         q.pop();
-        const GNode& g = b.nodes[gi];
+        const GNode& g = b.nodes[it.gnode];
         cost += (double)half_area(g.lo, g.hi) / root_area;
-        BvhNode out{};
-        out.pad[0] = out.pad[1] = 0;
-        const int32_t kids[2] = {g.left, g.right};
-        for (int c = 0; c < 2; ++c) {
-            const GNode& k = b.nodes[kids[c]];
-            set_child_box(out, c, k.lo, k.hi, hs.pad);
-            if (k.left < 0) {
-                if (k.count == 0 || k.count > (uint32_t)kMaxLeafTris) { err = "internal: bad leaf size"; return RT_ERR_INVALID; }
-                out.child[c] = leaf_code(k);
-                cost += (double)half_area(k.lo, k.hi) / root_area * (double)k.count;
+        int32_t kids[4] = {g.left, g.right, -1, -1};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < nk; ++k) {
+                const GNode& c = b.nodes[kids[k]];
+                if (c.left >= 0) {
+                    float ar = half_area(c.lo, c.hi);
+                    if (ar > best_area) best_area = ar, best = k;
+                }
+            }
+            if (best < 0) break;
+            const GNode& c = b.nodes[kids[best]];
+            kids[best] = c.left;
+            kids[nk++] = c.right;
+        }
+        BvhNode out = empty_node();
+        float klo[4][3], khi[4][3];
+        for (int k = 0; k < nk; ++k)
+            for (int a = 0; a < 3; ++a) klo[k][a] = b.nodes[kids[k]].lo[a] - hs.pad, khi[k][a] = b.nodes[kids[k]].hi[a] + hs.pad;
+        if (!quantise_node(out, nk, klo, khi)) { err = "internal: quantisation failed"; return RT_ERR_INVALID; }
+        for (int k = 0; k < nk; ++k) {
+            const GNode& c = b.nodes[kids[k]];
+            if (c.left < 0) {
+                if (c.count == 0 || c.count > (uint32_t)kMaxLeafTris) { err = "internal: bad leaf size"; return RT_ERR_INVALID; }
+                out.child[k] = leaf_code(c, it.depth + 1);
+                cost += (double)half_area(c.lo, c.hi) / root_area * (double)c.count;
             } else {
-                out.child[c] = (int32_t)hs.nodes.size();
-                hs.nodes.push_back(BvhNode{});
-                q.push({kids[c], out.child[c]});
+                out.child[k] = (int32_t)hs.nodes.size();
+                hs.nodes.push_back(empty_node());
+                q.push({kids[k], out.child[k], it.depth + 1});
             }
         }
-        hs.nodes[slot] = out;
+        hs.nodes[it.slot] = out;
     }
     hs.sah_cost = cost;
     if (hs.tris.size() != T) { err = "internal: triangle count mismatch after build"; return RT_ERR_INVALID; }
-    if (hs.max_depth + 1 >= (uint32_t)kStackSize) { err = "internal: BVH deeper than the traversal stack"; return RT_ERR_INVALID; }
+    // Exact worst-case traversal stack need: at every level all siblings of the entered child may be waiting.
+    std::function<uint32_t(int32_t)> need = [&](int32_t node) -> uint32_t {
+        const BvhNode& n = hs.nodes[node];
+        uint32_t nk = 0, worst = 0;
+        for (int k = 0; k < 4; ++k) nk += n.child[k] != kChildEmpty;
+        for (int k = 0; k < 4; ++k)
+            if (n.child[k] != kChildEmpty) worst = std::max(worst, (nk - 1) + (n.child[k] >= 0 ? need(n.child[k]) : 0u));
+        return worst;
+    };
+    hs.stack_need = need(0);
+    if (hs.stack_need + 1 >= (uint32_t)kStackSize) {
+        if (bvh_kind != RT_BVH_MEDIAN_INTERNAL) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // balanced fallback
+        err = "internal: BVH deeper than the traversal stack";
+        return RT_ERR_INVALID;
+    }
     return RT_OK;
 }
 
@@ -420,47 +505,55 @@ int check_bvh(const HostScene& hs, std::string& err) {
     const size_t T = hs.wverts.size() / 9;
     if (hs.nodes.empty()) { err = "no root node"; return RT_ERR_INVALID; }
     std::vector<uint8_t> seen(T, 0);
-    struct Item { int32_t child; float lo[3], hi[3]; uint32_t depth; };
-    std::vector<Item> st;
-    const float inf = std::numeric_limits<float>::infinity();
-    st.push_back(Item{0, {-inf, -inf, -inf}, {inf, inf, inf}, 0});
     size_t visited = 0;
-    while (!st.empty()) {
-        Item it = st.back();
-        st.pop_back();
-        if (it.depth >= (uint32_t)kStackSize) { err = "tree deeper than traversal stack"; return RT_ERR_INVALID; }
-        if (it.child >= 0) {
-            if ((size_t)it.child >= hs.nodes.size()) { err = "child index out of range"; return RT_ERR_INVALID; }
-            if (++visited > hs.nodes.size()) { err = "cycle in node graph"; return RT_ERR_INVALID; }
-            const BvhNode& n = hs.nodes[it.child];
-            for (int c = 0; c < 2; ++c) {
-                Item k;
-                k.child = n.child[c];
-                k.lo[0] = n.bx[2 * c], k.hi[0] = n.bx[2 * c + 1];
-                k.lo[1] = n.by[2 * c], k.hi[1] = n.by[2 * c + 1];
-                k.lo[2] = n.bz[2 * c], k.hi[2] = n.bz[2 * c + 1];
-                k.depth = it.depth + 1;
-                if (k.lo[0] > k.hi[0]) continue; // absent child
-                for (int a = 0; a < 3; ++a)
-                    if (k.lo[a] < it.lo[a] || k.hi[a] > it.hi[a]) { err = "child box escapes its parent"; return RT_ERR_INVALID; }
-                st.push_back(k);
+    bool ok = true;
+    const float inf = std::numeric_limits<float>::infinity();
+    // returns the exact bounds of everything below `child`; checks them against every decoded box above
+    struct B { float lo[3], hi[3]; };
+    auto fail = [&](const std::string& m) { if (ok) err = m; ok = false; };
+    std::function<B(int32_t, uint32_t)> walk = [&](int32_t child, uint32_t depth) -> B {
+        B r;
+        for (int a = 0; a < 3; ++a) r.lo[a] = inf, r.hi[a] = -inf;
+        if (!ok) return r;
+        if (depth >= (uint32_t)kStackSize) { fail("tree deeper than traversal stack"); return r; }
+        if (child >= 0) {
+            if ((size_t)child >= hs.nodes.size()) { fail("child index out of range"); return r; }
+            if (++visited > hs.nodes.size()) { fail("cycle in node graph"); return r; }
+            const BvhNode& n = hs.nodes[child];
+            for (int k = 0; k < 4; ++k) {
+                if (n.child[k] == kChildEmpty) continue;
+                B c = walk(n.child[k], depth + 1);
+                if (!ok) return r;
+                for (int a = 0; a < 3; ++a) {
+                    const float s = grid_step((n.exps >> (8 * a)) & 0xffu);
+                    const float dlo = n.origin[a] + (float)((n.q[2 * a] >> (8 * k)) & 0xffu) * s;
+                    const float dhi = n.origin[a] + (float)((n.q[2 * a + 1] >> (8 * k)) & 0xffu) * s;
+                    // the decoded box must contain the subtree with at least half the builder's pad to spare
+                    if (!(dlo <= c.lo[a] - 0.5f * hs.pad) || !(dhi >= c.hi[a] + 0.5f * hs.pad)) {
+                        fail("decoded child box does not contain its subtree (node " + std::to_string(child) + ")");
+                        return r;
+                    }
+                    r.lo[a] = std::min(r.lo[a], c.lo[a]), r.hi[a] = std::max(r.hi[a], c.hi[a]);
+                }
             }
         } else {
-            uint32_t code = (uint32_t)~it.child;
+            uint32_t code = (uint32_t)~child;
             uint32_t first = code >> 2, count = (code & 3u) + 1u;
-            if ((size_t)first + count > hs.tris.size()) { err = "leaf range out of bounds"; return RT_ERR_INVALID; }
+            if ((size_t)first + count > hs.tris.size()) { fail("leaf range out of bounds"); return r; }
             for (uint32_t k = 0; k < count; ++k) {
                 const TriRec& tr = hs.tris[first + k];
-                if (tr.global_index >= T) { err = "leaf triangle has bad global index"; return RT_ERR_INVALID; }
-                if (seen[tr.global_index]++) { err = "triangle appears in two leaves"; return RT_ERR_INVALID; }
+                if (tr.global_index >= T) { fail("leaf triangle has bad global index"); return r; }
+                if (seen[tr.global_index]++) { fail("triangle appears in two leaves"); return r; }
                 const float* w = &hs.wverts[9 * (size_t)tr.global_index];
+                if (tr.v0[0] != w[0] || tr.v0[1] != w[1] || tr.v0[2] != w[2]) { fail("leaf triangle data mismatch"); return r; }
                 for (int v = 0; v < 3; ++v)
-                    for (int a = 0; a < 3; ++a)
-                        if (w[3 * v + a] < it.lo[a] || w[3 * v + a] > it.hi[a]) { err = "triangle vertex outside its leaf box"; return RT_ERR_INVALID; }
-                if (tr.v0[0] != w[0] || tr.v0[1] != w[1] || tr.v0[2] != w[2]) { err = "leaf triangle data mismatch"; return RT_ERR_INVALID; }
+                    for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], w[3 * v + a]), r.hi[a] = std::max(r.hi[a], w[3 * v + a]);
             }
         }
-    }
+        return r;
+    };
+    (void)walk(0, 0);
+    if (!ok) return RT_ERR_INVALID;
     for (size_t t = 0; t < T; ++t)
         if (!seen[t]) { err = "triangle " + std::to_string(t) + " is in no leaf"; return RT_ERR_INVALID; }
     return RT_OK;

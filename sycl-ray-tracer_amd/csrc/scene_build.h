@@ -22,9 +22,11 @@ struct HostScene {
     float sky[3] = {0.5f, 0.7f, 1.0f};
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
     float pad = 0.0f;             // absolute box padding used by the builder
-    uint32_t max_depth = 0, max_leaf_tris = 0;
+    uint32_t max_depth = 0, max_leaf_tris = 0, stack_need = 0;
     double sah_cost = 0.0;
 };
+
+constexpr int RT_BVH_MEDIAN_INTERNAL = 99; // balanced fallback when a tree would overflow the traversal stack
 
 // Validates `desc` and fills `out`. Returns RT_OK or RT_ERR_INVALID with `err` set.
 int build_host_scene(const rt_scene_desc* desc, int bvh_kind, HostScene& out, std::string& err);
