@@ -181,7 +181,29 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d) {
     T.sp = 0;
 }
 
-RT_DEV void trav_pop(Trav& T, const int32_t* stack) { T.cur = T.sp > 0 ? stack[--T.sp] : kTravDone; }
+// Traversal stack: the first kLdsStack entries of every lane live in LDS (entry-major, lane-minor:
+// conflict-free ds_read/ds_write_b32), deeper entries spill to per-lane scratch (rare). The first
+// version kept the whole stack in scratch: every push/pop was an L1 access and a write to HBM.
+constexpr int kLdsStack = 16;
+typedef __attribute__((address_space(3))) int32_t lds_i32; // forces ds_read/ds_write (never flat_*)
+struct TravStack {
+    lds_i32* lds;   // this lane's column: entry e at lds[e * stride]
+    int32_t* spill; // kStackSize - kLdsStack entries of scratch
+    int stride;     // threads per block
+};
+RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) {
+    if (T.sp < kLdsStack) st.lds[T.sp * st.stride] = v;
+    else st.spill[T.sp - kLdsStack] = v;
+    T.sp++;
+}
+RT_DEV void trav_pop(Trav& T, const TravStack& st) {
+    if (T.sp > 0) {
+        T.sp--;
+        T.cur = T.sp < kLdsStack ? st.lds[T.sp * st.stride] : st.spill[T.sp - kLdsStack];
+    } else {
+        T.cur = kTravDone;
+    }
+}
 
 // byte k of a word as float (v_cvt_f32_ubyteK)
 RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
@@ -194,7 +216,7 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 //   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
 // The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
 // min/max pairing is needed.
-RT_DEV void trav_inner(const SceneDev& S, Trav& T, int32_t* stack) {
+RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint4* np = reinterpret_cast<const uint4*>(S.nodes + T.cur);
     const uint4 w0 = np[0], w1 = np[1];
     const uint2 w2 = *reinterpret_cast<const uint2*>(np + 2);
@@ -239,15 +261,15 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, int32_t* stack) {
     RT_CE(k1, c1, k3, c3)
     RT_CE(k1, c1, k2, c2)
 #undef RT_CE
-    if (k3 < inf) stack[T.sp++] = c3; // farthest first
-    if (k2 < inf) stack[T.sp++] = c2;
-    if (k1 < inf) stack[T.sp++] = c1;
+    if (k3 < inf) stk_push(stack, T, c3); // farthest first
+    if (k2 < inf) stk_push(stack, T, c2);
+    if (k1 < inf) stk_push(stack, T, c1);
     if (k0 < inf) T.cur = c0;
     else trav_pop(T, stack);
 }
 
 // leaf step: test ONE triangle of the leaf, then move to the next one or pop
-RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const int32_t* stack) {
+RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;
     const uint32_t first = code >> 2, rem = code & 3u;
     tri_test(S.tris + first, T.o, T.d, T.best);
@@ -256,7 +278,7 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const int32_t* stack) {
 }
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
-RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, int32_t* stack) {
+RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack) {
     const bool inner = T.cur >= 0;
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
@@ -269,7 +291,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, int32_t* stack) {
 }
 
 // run to completion (rt_intersect_batch; lanes that finish early wait for the wave)
-RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, int32_t* stack) {
+RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, const TravStack& stack) {
     Trav T;
     trav_begin(T, o, d);
     while (trav_step_wave(S, T, stack)) {}

@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(64) k_megakernel(SceneDev S, CameraDev cam, Ti
     f3 color = mk3(0.0f, 0.0f, 0.0f);
     RayState r{};
     Trav T;
-    int32_t stack[kStackSize];
+    __shared__ int32_t lds_stack[kLdsStack * 64];
+    int32_t spill[kStackSize - kLdsStack];
+    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 64};
     T.cur = kTravDone;
     bool live = false; // this lane still has samples to finish
     if (active) {
@@ -181,7 +183,9 @@ __global__ void __launch_bounds__(256) k_wf_shoot(SceneDev S, QueueDev qin, Queu
     bool survive = false;
     RayState r{};
     uint32_t id = 0;
-    int32_t stack[kStackSize];
+    __shared__ int32_t lds_stack[kLdsStack * 256];
+    int32_t spill[kStackSize - kLdsStack];
+    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 256};
     Trav T;
     T.cur = kTravDone;
     if (i < n) {
@@ -241,7 +245,9 @@ __global__ void __launch_bounds__(256) k_intersect_batch(SceneDev S, uint32_t n,
                                                           uint32_t* __restrict__ tri) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    int32_t stack[kStackSize];
+    __shared__ int32_t lds_stack[kLdsStack * 256];
+    int32_t spill[kStackSize - kLdsStack];
+    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 256};
     const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), stack);
     t[i] = h.t, u[i] = h.u, v[i] = h.v, tri[i] = h.tri;
 }
