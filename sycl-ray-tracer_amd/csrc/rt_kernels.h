@@ -72,7 +72,11 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 //             sample (new camera ray) or retire the pixel.
 // A lane therefore never idles while another lane finishes a long traversal or a long path; per-pixel
 // arithmetic and its order are unchanged (bit-exact with the per-pixel loops of the reference).
-__global__ void __launch_bounds__(64) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+// 6 waves/SIMD (80 VGPRs) measured best: 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
+#ifndef RT_MEGA_WAVES
+#define RT_MEGA_WAVES 6
+#endif
+__global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter) {

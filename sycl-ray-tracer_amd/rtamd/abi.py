@@ -147,7 +147,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("RT_MI355X_LIB", LIB_PATH))  # env override: A/B builds
     if not p.exists():
         raise FileNotFoundError(
             f"{p} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
