@@ -76,17 +76,18 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 6
 #endif
+template <bool STATS>
 __global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
-                                                    unsigned long long* __restrict__ ray_counter) {
-    const int tiles_x = (cam.width + 7) >> 3;
-    const int tx = (int)(blockIdx.x % (uint32_t)tiles_x), ty = (int)(blockIdx.x / (uint32_t)tiles_x);
+                                                    unsigned long long* __restrict__ ray_counter,
+                                                    unsigned long long* __restrict__ stats_out) {
+    WaveStats ws;
+    const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
+    const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)threadIdx.x;
-    const int x = tx * 8 + (lane & 7);
-    const int ly = ty * 8 + (lane >> 3); // local row
-    const int gy = tile_global_row(tile, ly);
-    const bool active = x < cam.width && ly < tile.local_rows && gy < cam.height;
+    uint32_t* pixel_cursor = reinterpret_cast<uint32_t*>(ray_counter + 1);
+    int x = 0, ly = 0, gy = 0;
     uint32_t rays = 0, rng = 0, s = 0, depth = 0;
     f3 color = mk3(0.0f, 0.0f, 0.0f);
     RayState r{};
@@ -95,26 +96,50 @@ __global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, Ca
     int32_t spill[kStackSize - kLdsStack];
     const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 64};
     T.cur = kTravDone;
-    bool live = false; // this lane still has samples to finish
-    if (active) {
-        rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
-        if (max_depth == 0) {
-            for (uint32_t i = 0; i < spp; ++i) (void)camera_ray(cam, x, gy, rng);
-        } else {
-            live = true;
-            r = camera_ray(cam, x, gy, rng);
-            trav_begin(T, r.org, ray_dir(r));
-        }
-    }
+    bool live = false;      // this lane owns a pixel with samples left
+    bool exhausted = false; // wave-uniform: the pixel cursor has passed the last slot
     for (;;) {
-        // TRAVERSE until at most half of the live lanes are still traversing
+        // REFILL: idle lanes take the next pixels from the frame-wide cursor, one atomic per wave and round.
+        // A wave is persistent: it keeps pulling pixels until the frame is exhausted, so a lane whose
+        // pixel was cheap (sky) does not idle while its neighbours finish 640-ray pixels.
+        if (!exhausted) {
+            const unsigned long long idle_m = __ballot(!live);
+            const uint32_t cnt = (uint32_t)__popcll(idle_m);
+            if (cnt >= 16u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (!live && p < n_slots) {
+                    const uint32_t t = p >> 6;
+                    x = (int)((t % tiles_x) * 8u + (p & 7u));
+                    ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
+                    gy = tile_global_row(tile, ly);
+                    if (x < cam.width && ly < tile.local_rows && gy < cam.height) {
+                        rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
+                        color = mk3(0.0f, 0.0f, 0.0f);
+                        s = 0, depth = 0;
+                        r = camera_ray(cam, x, gy, rng);
+                        trav_begin(T, r.org, ray_dir(r));
+                        live = true;
+                    }
+                }
+                exhausted = base + cnt >= n_slots;
+            }
+        }
         const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
-        if (n_live == 0) break;
+        if (n_live == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // TRAVERSE until at least half of the live lanes are waiting for shading
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 2u >= n_live) break;
-            (void)trav_step_wave(S, T, stack);
+            if (STATS) ws.live_lane_steps += n_live;
+            (void)trav_step_wave<STATS>(S, T, stack, &ws);
         }
+        if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
         // SHADE the lanes whose traversal is complete
         if (live && T.cur == kTravDone) {
             f3 res;
@@ -125,23 +150,38 @@ __global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, Ca
                 if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
                 s++;
                 depth = 0;
-                if (s < spp) r = camera_ray(cam, x, gy, rng);
-                else live = false;
+                if (s < spp) {
+                    r = camera_ray(cam, x, gy, rng);
+                } else { // pixel finished: mean, sqrt gamma, fp32 + unorm8 stores (src/render_megakernel.cpp:154-158)
+                    live = false;
+                    const float n = (float)spp;
+                    const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
+                    const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
+                    if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                    if (out_u8)
+                        reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+                                                                 ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+                }
             }
             if (live) trav_begin(T, r.org, ray_dir(r));
         }
     }
-    if (active) {
-        const float n = (float)spp;
-        const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
-        const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
-        if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
-        if (out_u8)
-            reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
-                                                     ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
-    }
     const uint32_t total = wave_sum_u32(rays);
     if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
+    if (STATS && lane == 0) {
+        atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
+        atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
+        atomicAdd(stats_out + 4, (unsigned long long)ws.shade_rounds), atomicAdd(stats_out + 5, (unsigned long long)ws.shade_lanes);
+        atomicAdd(stats_out + 6, (unsigned long long)ws.live_lane_steps);
+    }
+}
+
+// max_depth == 0: render_pixel traces nothing (src/render_megakernel.cpp:31) -> black frame, zero rays
+__global__ void __launch_bounds__(256) k_fill_black(uint32_t n_local, float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_local) return;
+    if (out_f32) reinterpret_cast<float4*>(out_f32)[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (out_u8) reinterpret_cast<uint32_t*>(out_u8)[i] = 0xff000000u;
 }
 
 // ---- K2: seed RNG states, zero the accumulator --------------------------------------------------------

@@ -74,12 +74,14 @@ struct rt_renderer {
     uint32_t max_depth = 0, spp = 0, seed_mode = 0;
     TileDev tile{0, 1, 8, 0};
     uint32_t n_local = 0; // pixels in this tile
+    int n_cus = 256;      // compute units of the device (persistent-kernel grid sizing)
     hipStream_t stream = nullptr;
     // outputs (device) used when the caller passes host pointers
     float* d_f32 = nullptr;
     uint8_t* d_u8 = nullptr;
     // megakernel
     unsigned long long* d_ray_counter = nullptr;
+    unsigned long long* d_stats = nullptr; // RT_KERNEL_STATS=1: wave scheduling statistics (diagnostic)
     // wavefront
     QueueDev q[2]{};
     uint32_t* d_rng = nullptr;
@@ -98,7 +100,7 @@ void free_tile_buffers(rt_renderer* r) {
         if (p) (void)hipFree((void*)p);
         p = nullptr;
     };
-    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_rng), fr(r->d_accum), fr(r->d_counts);
+    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats), fr(r->d_rng), fr(r->d_accum), fr(r->d_counts);
     for (auto& q : r->q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
 }
 
@@ -113,7 +115,9 @@ int alloc_tile_buffers(rt_renderer* r) {
     HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
     HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMalloc((void**)&r->d_ray_counter, sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 2 * sizeof(unsigned long long)));
+        const char* ks = std::getenv("RT_KERNEL_STATS");
+        if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 8 * sizeof(unsigned long long)));
     } else {
         for (auto& q : r->q) {
             HIPCHK(hipMalloc((void**)&q.org_id, n * 16));
@@ -159,13 +163,23 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         return RT_OK;
     }
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 2 * sizeof(unsigned long long), st)); // ray count + pixel cursor
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
+        // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
+        const uint32_t grid = std::min<uint32_t>(tiles_x * tiles_y, (uint32_t)r->n_cus * 4u * RT_MEGA_WAVES);
         hipEvent_t e0 = pool_event(r, 0), e1 = pool_event(r, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
         HIPCHK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(k_megakernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, S, c, r->tile, r->max_depth, r->spp,
-                           r->seed_mode, d_f32, d_u8, r->d_ray_counter);
+        if (r->max_depth == 0) {
+            hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
+        } else if (r->d_stats) {
+            HIPCHK(hipMemsetAsync(r->d_stats, 0, 8 * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(64), 0, st, S, c, r->tile, r->max_depth,
+                               r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+        } else {
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(64), 0, st, S, c, r->tile, r->max_depth,
+                               r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
         *n_hot_events = 2;
@@ -237,6 +251,16 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
             unsigned long long rays = 0;
             HIPCHK(hipMemcpy(&rays, r->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
             local.rays = rays;
+            if (r->d_stats) {
+                unsigned long long h[8];
+                HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+                std::fprintf(stderr,
+                             "[rt stats] rays %llu | inner steps %llu (%.1f lanes/step) | leaf steps %llu (%.1f lanes/step) | "
+                             "shade rounds %llu (%.1f lanes/round) | live lanes/step %.1f | per ray: %.2f inner, %.2f tri\n",
+                             rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
+                             h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
+                             rays ? (double)h[1] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
+            }
         } else {
             HIPCHK(hipMemcpy(r->h_counts.data(), r->d_counts, r->h_counts.size() * 4, hipMemcpyDeviceToHost));
             uint64_t rays = 0;
@@ -414,6 +438,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         rt_renderer_destroy(r);
         return code;
     };
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess && prop.multiProcessorCount > 0) r->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
