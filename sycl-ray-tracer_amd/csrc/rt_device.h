@@ -280,7 +280,7 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
 // wave-level scheduling statistics (diagnostic builds of the kernels only: RT_KERNEL_STATS=1)
 struct WaveStats {
     uint32_t inner_steps = 0, inner_lanes = 0, leaf_steps = 0, leaf_lanes = 0;
-    uint32_t shade_rounds = 0, shade_lanes = 0, live_lane_steps = 0;
+    uint32_t shade_rounds = 0, shade_lanes = 0, live_lane_steps = 0, top_lanes = 0;
 };
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
@@ -290,7 +290,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
     if (ni >= nl) {
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni;
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < 341));
         if (inner) trav_inner(S, T, stack);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += nl;

@@ -86,7 +86,8 @@ struct rt_renderer {
     QueueDev q[2]{};
     uint32_t* d_rng = nullptr;
     float4* d_accum = nullptr;
-    uint32_t* d_counts = nullptr; // spp * (max_depth + 1)
+    uint32_t* d_counts = nullptr; // spp * (max_depth + 1) queue lengths, then spp * max_depth extend cursors
+    float4* d_hits = nullptr;     // closest-hit record per queue slot
     std::vector<uint32_t> h_counts;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profile_kernels = false;
@@ -100,7 +101,7 @@ void free_tile_buffers(rt_renderer* r) {
         if (p) (void)hipFree((void*)p);
         p = nullptr;
     };
-    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats), fr(r->d_rng), fr(r->d_accum), fr(r->d_counts);
+    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats), fr(r->d_rng), fr(r->d_accum), fr(r->d_counts), fr(r->d_hits);
     for (auto& q : r->q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
 }
 
@@ -112,12 +113,12 @@ int alloc_tile_buffers(rt_renderer* r) {
     r->tile.local_rows = rows;
     r->n_local = (uint32_t)rows * (uint32_t)r->width;
     const size_t n = std::max<size_t>(r->n_local, 1);
+    const char* ks = std::getenv("RT_KERNEL_STATS");
+    if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 8 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
     HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(hipMalloc((void**)&r->d_ray_counter, 2 * sizeof(unsigned long long)));
-        const char* ks = std::getenv("RT_KERNEL_STATS");
-        if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 8 * sizeof(unsigned long long)));
     } else {
         for (auto& q : r->q) {
             HIPCHK(hipMalloc((void**)&q.org_id, n * 16));
@@ -127,8 +128,9 @@ int alloc_tile_buffers(rt_renderer* r) {
         }
         HIPCHK(hipMalloc((void**)&r->d_rng, n * 4));
         HIPCHK(hipMalloc((void**)&r->d_accum, n * 16));
+        HIPCHK(hipMalloc((void**)&r->d_hits, n * 16));
         const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
-        HIPCHK(hipMalloc((void**)&r->d_counts, nc * 4));
+        HIPCHK(hipMalloc((void**)&r->d_counts, (nc + (size_t)r->spp * r->max_depth + 1) * 4));
         r->h_counts.resize(nc);
     }
     return RT_OK;
@@ -187,7 +189,15 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
     } else {
         const uint32_t grid = (r->n_local + 255u) / 256u;
         const uint32_t D = r->max_depth;
-        HIPCHK(hipMemsetAsync(r->d_counts, 0, r->h_counts.size() * 4, st));
+        if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 8 * sizeof(unsigned long long), st));
+        const size_t n_cursors = (size_t)r->spp * D;
+        HIPCHK(hipMemsetAsync(r->d_counts, 0, (r->h_counts.size() + n_cursors) * 4, st));
+        uint32_t* cursors = r->d_counts + r->h_counts.size();
+        // persistent EXTEND waves: fill every SIMD at the kernel's occupancy, never more than there are chunks
+        constexpr uint32_t ext_wpb = RT_EXTEND_BLOCK / 64;
+        const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((r->n_local + kExtendChunk - 1u) / kExtendChunk,
+                                                                            (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
+        const uint32_t ext_grid = (ext_waves + ext_wpb - 1u) / ext_wpb;
         hipLaunchKernelGGL(k_wf_init, dim3(grid), dim3(256), 0, st, c, r->tile, r->seed_mode, r->n_local, r->d_rng, r->d_accum);
         launches++;
         size_t ne = 0;
@@ -203,13 +213,19 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                     if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
                     HIPCHK(hipEventRecord(e0, st));
                 }
-                hipLaunchKernelGGL(k_wf_shoot, dim3(grid), dim3(256), 0, st, S, r->q[buf], r->q[buf ^ 1], r->d_rng, r->d_accum,
-                                   counts + d, counts + d + 1, d + 1 == D ? 1 : 0);
+                if (r->d_stats)
+                    hipLaunchKernelGGL(k_wf_extend<true>, dim3(ext_grid), dim3(RT_EXTEND_BLOCK), 0, st, S, r->q[buf], r->d_hits,
+                                       counts + d, cursors + (size_t)s * D + d, r->d_stats);
+                else
+                    hipLaunchKernelGGL(k_wf_extend<false>, dim3(ext_grid), dim3(RT_EXTEND_BLOCK), 0, st, S, r->q[buf], r->d_hits,
+                                       counts + d, cursors + (size_t)s * D + d, (unsigned long long*)nullptr);
                 if (r->profile_kernels) {
                     HIPCHK(hipEventRecord(e1, st));
                     ne += 2;
                 }
-                launches++;
+                hipLaunchKernelGGL(k_wf_shade, dim3(grid), dim3(256), 0, st, S, r->q[buf], r->q[buf ^ 1], r->d_hits, r->d_rng,
+                                   r->d_accum, counts + d, counts + d + 1, d + 1 == D ? 1 : 0);
+                launches += 2;
                 buf ^= 1;
             }
         }
@@ -251,16 +267,6 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
             unsigned long long rays = 0;
             HIPCHK(hipMemcpy(&rays, r->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
             local.rays = rays;
-            if (r->d_stats) {
-                unsigned long long h[8];
-                HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-                std::fprintf(stderr,
-                             "[rt stats] rays %llu | inner steps %llu (%.1f lanes/step) | leaf steps %llu (%.1f lanes/step) | "
-                             "shade rounds %llu (%.1f lanes/round) | live lanes/step %.1f | per ray: %.2f inner, %.2f tri\n",
-                             rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
-                             h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
-                             rays ? (double)h[1] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
-            }
         } else {
             HIPCHK(hipMemcpy(r->h_counts.data(), r->d_counts, r->h_counts.size() * 4, hipMemcpyDeviceToHost));
             uint64_t rays = 0;
@@ -269,6 +275,17 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
                 for (uint32_t d = 0; d < D; ++d) rays += r->h_counts[(size_t)s * (D + 1) + d]; // :407
             local.rays = rays;
         }
+    }
+    if (r->d_stats && r->n_local) {
+        unsigned long long h[8];
+        const unsigned long long rays = local.rays;
+        HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        std::fprintf(stderr,
+                     "[rt stats] rays %llu | inner steps %llu (%.1f lanes/step) | leaf steps %llu (%.1f lanes/step) | "
+                     "shade/refill rounds %llu (%.1f lanes/round) | live lanes/step %.1f | per ray: %.2f inner (%.2f in the top 341 nodes), %.2f tri\n",
+                     rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
+                     h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
+                     rays ? (double)h[1] / rays : 0.0, rays ? (double)h[7] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
     }
     if (stats) *stats = local;
     return RT_OK;
