@@ -184,7 +184,10 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d) {
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (entry-major, lane-minor:
 // conflict-free ds_read/ds_write_b32), deeper entries spill to per-lane scratch (rare). The first
 // version kept the whole stack in scratch: every push/pop was an L1 access and a write to HBM.
-constexpr int kLdsStack = 16;
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12
+#endif
+constexpr int kLdsStack = RT_LDS_STACK;
 typedef __attribute__((address_space(3))) int32_t lds_i32; // forces ds_read/ds_write (never flat_*)
 struct TravStack {
     lds_i32* lds;   // this lane's column: entry e at lds[e * stride]
@@ -205,6 +208,38 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) {
     }
 }
 
+// The first kTopNodes nodes of the breadth-first node array (the top ~5 levels of the BVH4) are staged in
+// LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes so that the 16-byte
+// reads of different nodes spread over the banks. Measured on the atrium: 9.5 of the 17.9 inner-node
+// visits of an average ray fall into these nodes; taking them out of the vector L1 path (the first
+// versions were bound by L1 tag throughput: ~1 lane-load per cycle and CU) is worth more than any ALU saving.
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 341
+#endif
+constexpr int kTopNodes = RT_TOP_NODES;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+struct TopTree {
+    lds_u32x4* w0; // origin.xyz, exps
+    lds_u32x4* w1; // qlo_x, qhi_x, qlo_y, qhi_y
+    lds_u32x2* w2; // qlo_z, qhi_z
+    lds_u32x4* ch; // child[4]
+    int32_t count; // nodes staged (0 = none)
+};
+// cooperative fill by the whole workgroup; the caller synchronises afterwards
+RT_DEV void top_tree_fill(const SceneDev& S, u32x4* w0, u32x4* w1, u32x2* w2, u32x4* ch, int32_t count) {
+    for (int32_t i = (int32_t)threadIdx.x; i < count; i += (int32_t)blockDim.x) {
+        const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + i);
+        w0[i] = np[0];
+        w1[i] = np[1];
+        const u32x4 t = np[2];
+        w2[i] = u32x2{t.x, t.y};
+        ch[i] = np[3];
+    }
+}
+
 // byte k of a word as float (v_cvt_f32_ubyteK)
 RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
 RT_DEV float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
@@ -216,11 +251,18 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 //   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
 // The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
 // min/max pairing is needed.
-RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack) {
-    const uint4* np = reinterpret_cast<const uint4*>(S.nodes + T.cur);
-    const uint4 w0 = np[0], w1 = np[1];
-    const uint2 w2 = *reinterpret_cast<const uint2*>(np + 2);
-    const int4 ch = *reinterpret_cast<const int4*>(np + 3);
+RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top) {
+    u32x4 w0, w1, chw;
+    u32x2 w2;
+    if (T.cur < top.count) { // top of the tree: LDS
+        w0 = top.w0[T.cur], w1 = top.w1[T.cur], w2 = top.w2[T.cur], chw = top.ch[T.cur];
+    } else {
+        const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + T.cur);
+        w0 = np[0], w1 = np[1];
+        w2 = *reinterpret_cast<const u32x2*>(np + 2);
+        chw = np[3];
+    }
+    const int4 ch = make_int4((int)chw.x, (int)chw.y, (int)chw.z, (int)chw.w);
     const float ax = __uint_as_float((w0.w & 0xffu) << 23) * T.ix;
     const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * T.iy;
     const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * T.iz;
@@ -285,13 +327,13 @@ struct WaveStats {
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
 template <bool STATS = false>
-RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, WaveStats* ws = nullptr) {
+RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, WaveStats* ws = nullptr) {
     const bool inner = T.cur >= 0;
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
     if (ni >= nl) {
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < 341));
-        if (inner) trav_inner(S, T, stack);
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes));
+        if (inner) trav_inner(S, T, stack, top);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += nl;
         if (leaf) trav_leaf(S, T, stack);
@@ -300,10 +342,10 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 }
 
 // run to completion (rt_intersect_batch; lanes that finish early wait for the wave)
-RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, const TravStack& stack) {
+RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, const TravStack& stack, const TopTree& top) {
     Trav T;
     trav_begin(T, o, d);
-    while (trav_step_wave(S, T, stack)) {}
+    while (trav_step_wave(S, T, stack, top)) {}
     return T.best;
 }
 

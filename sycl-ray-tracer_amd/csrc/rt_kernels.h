@@ -41,6 +41,18 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     return __float_as_uint(o.w);
 }
 
+// LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
+#define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
+    __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_ch[kTopNodes];                          \
+    __shared__ u32x2 top_w2[kTopNodes];                                                                \
+    __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
+    int32_t spill[kStackSize - kLdsStack];                                                             \
+    const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
+    top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
+    __syncthreads();                                                                                   \
+    const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x2*)top_w2, (lds_u32x4*)top_ch, top_count}; \
+    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, (BLOCK)};
+
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
 // the part of one bounce after the closest-hit query: unpack halves -> shade_hit -> repack (the body of
@@ -77,8 +89,11 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 6
 #endif
+#ifndef RT_MEGA_BLOCK
+#define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
@@ -86,16 +101,14 @@ __global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, Ca
     WaveStats ws;
     const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
     uint32_t* pixel_cursor = reinterpret_cast<uint32_t*>(ray_counter + 1);
     int x = 0, ly = 0, gy = 0;
     uint32_t rays = 0, rng = 0, s = 0, depth = 0;
     f3 color = mk3(0.0f, 0.0f, 0.0f);
     RayState r{};
     Trav T;
-    __shared__ int32_t lds_stack[kLdsStack * 64];
-    int32_t spill[kStackSize - kLdsStack];
-    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 64};
+    RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
     bool exhausted = false; // wave-uniform: the pixel cursor has passed the last slot
@@ -138,7 +151,7 @@ __global__ void __launch_bounds__(64, RT_MEGA_WAVES) k_megakernel(SceneDev S, Ca
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 2u >= n_live) break;
             if (STATS) ws.live_lane_steps += n_live;
-            (void)trav_step_wave<STATS>(S, T, stack, &ws);
+            (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
         }
         if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
         // SHADE the lanes whose traversal is complete
@@ -228,7 +241,7 @@ constexpr uint32_t kExtendRefill = 16;
 #define RT_EXTEND_WAVES 8
 #endif
 #ifndef RT_EXTEND_BLOCK
-#define RT_EXTEND_BLOCK 64
+#define RT_EXTEND_BLOCK 1024
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(SceneDev S, QueueDev qin, float4* __restrict__ hits,
@@ -241,9 +254,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
     constexpr uint32_t kWavesPerBlock = RT_EXTEND_BLOCK / 64;
     const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); // waves of a block are independent
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    __shared__ int32_t lds_stack[kLdsStack * RT_EXTEND_BLOCK];
-    int32_t spill[kStackSize - kLdsStack];
-    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, RT_EXTEND_BLOCK};
+    RT_TRAVERSAL_LDS(RT_EXTEND_BLOCK)
     Trav T;
     T.cur = kTravDone;
     bool has = false;     // this lane holds a ray whose hit has not been written yet
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
     uint32_t chunk_pos = wave_id * kExtendChunk;
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
     bool exhausted = chunk_pos >= n;
-    if (exhausted) return;
+    if (exhausted) return; // (after the workgroup barrier of the LDS fill)
     for (;;) {
         // start the rays whose data was requested in the previous round: the loads have been in flight
         // for a whole traversal step of the other lanes instead of stalling the wave at the request
@@ -305,7 +316,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
             continue;
         }
         if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-        (void)trav_step_wave<STATS>(S, T, stack, &ws);
+        (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
     }
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
@@ -385,12 +396,10 @@ __global__ void __launch_bounds__(256) k_intersect_batch(SceneDev S, uint32_t n,
                                                           const float* __restrict__ dir, float* __restrict__ t,
                                                           float* __restrict__ u, float* __restrict__ v,
                                                           uint32_t* __restrict__ tri) {
+    RT_TRAVERSAL_LDS(256)
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    __shared__ int32_t lds_stack[kLdsStack * 256];
-    int32_t spill[kStackSize - kLdsStack];
-    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, 256};
-    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), stack);
+    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), stack, top);
     t[i] = h.t, u[i] = h.u, v[i] = h.v, tri[i] = h.tri;
 }
 

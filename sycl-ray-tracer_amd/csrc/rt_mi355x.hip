@@ -168,7 +168,9 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 2 * sizeof(unsigned long long), st)); // ray count + pixel cursor
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
-        const uint32_t grid = std::min<uint32_t>(tiles_x * tiles_y, (uint32_t)r->n_cus * 4u * RT_MEGA_WAVES);
+        constexpr uint32_t mega_wpb = RT_MEGA_BLOCK / 64;
+        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
+                                                                        (uint32_t)r->n_cus * 4u * RT_MEGA_WAVES / mega_wpb));
         hipEvent_t e0 = pool_event(r, 0), e1 = pool_event(r, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
         HIPCHK(hipEventRecord(e0, st));
@@ -176,10 +178,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 8 * sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(64), 0, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(64), 0, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
