@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <deque>
 #include <functional>
 #include <queue>
 
@@ -426,7 +427,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     const double root_area = std::max(1e-30, (double)half_area(g0.lo, g0.hi));
     double cost = 0.0;
     struct Item { int32_t gnode; int32_t slot; uint32_t depth; };
-    std::queue<Item> q;
+    std::deque<Item> q;
     hs.nodes.push_back(empty_node());
     if (g0.left < 0) { // a single leaf: give the root one leaf child
         if (g0.count > (uint32_t)kMaxLeafTris) { err = "internal: oversized root leaf"; return RT_ERR_INVALID; }
@@ -439,10 +440,15 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         hs.sah_cost = (double)g0.count;
         return RT_OK;
     }
-    q.push({0, 0, 0});
+    // Emission order: breadth-first until the LDS-staged top of the tree is complete (the first nodes of the
+    // array are the shallowest ones), depth-first below it, so that the nodes and the triangles of one
+    // subtree are contiguous in memory (fewer distinct cache lines per ray than a pure breadth-first layout).
+    constexpr size_t kBfsNodes = 341;
+    q.push_back({0, 0, 0});
     while (!q.empty()) {
-        const Item it = q.front();
-        q.pop();
+        Item it;
+        if (hs.nodes.size() < kBfsNodes) { it = q.front(); q.pop_front(); }
+        else { it = q.back(); q.pop_back(); }
         const GNode& g = b.nodes[it.gnode];
         cost += (double)half_area(g.lo, g.hi) / root_area;
         int32_t kids[4] = {g.left, g.right, -1, -1};
@@ -463,6 +469,8 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
             kids[nk++] = c.right;
         }
         BvhNode out = empty_node();
+        Item pending[4];
+        int n_pending = 0;
         float klo[4][3], khi[4][3];
         for (int k = 0; k < nk; ++k)
             for (int a = 0; a < 3; ++a) klo[k][a] = b.nodes[kids[k]].lo[a] - hs.pad, khi[k][a] = b.nodes[kids[k]].hi[a] + hs.pad;
@@ -476,9 +484,12 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
             } else {
                 out.child[k] = (int32_t)hs.nodes.size();
                 hs.nodes.push_back(empty_node());
-                q.push({kids[k], out.child[k], it.depth + 1});
+                pending[n_pending++] = {kids[k], out.child[k], it.depth + 1};
             }
         }
+        // breadth-first phase: children in order at the back; depth-first phase: reversed, so child 0 is next
+        if (hs.nodes.size() < kBfsNodes) for (int k = 0; k < n_pending; ++k) q.push_back(pending[k]);
+        else for (int k = n_pending - 1; k >= 0; --k) q.push_back(pending[k]);
         hs.nodes[it.slot] = out;
     }
     hs.sah_cost = cost;
