@@ -274,19 +274,22 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     const uint32_t qny = ny ? w1.w : w1.z, qfy = ny ? w1.z : w1.w;
     const uint32_t qnz = nz ? w2.y : w2.x, qfz = nz ? w2.x : w2.y;
     const float inf = __builtin_huge_valf();
+    // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
+    // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 was
+    // measured 3 % slower than scalar v_fma_f32 here.)
     float k0, k1, k2, k3;
-#define RT_CHILD(K, CVT, CH)                                                                              \
+#define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
                                          __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
-        K = (tn <= tf && (CH) != kChildEmpty) ? tn : inf;                                                \
+        K = tn <= tf ? tn : inf;                                                                         \
     }
-    RT_CHILD(k0, ub0, ch.x)
-    RT_CHILD(k1, ub1, ch.y)
-    RT_CHILD(k2, ub2, ch.z)
-    RT_CHILD(k3, ub3, ch.w)
+    RT_CHILD(k0, ub0)
+    RT_CHILD(k1, ub1)
+    RT_CHILD(k2, ub2)
+    RT_CHILD(k3, ub3)
 #undef RT_CHILD
     int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
     // 5-comparator sorting network on (entry distance, child); misses carry +inf and sink to the end

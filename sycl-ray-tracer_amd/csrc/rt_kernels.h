@@ -89,6 +89,12 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 6
 #endif
+#ifndef RT_MEGA_REFILL
+#define RT_MEGA_REFILL 8u // idle lanes that trigger a pixel fetch
+#endif
+#ifndef RT_MEGA_SHADE_PCT
+#define RT_MEGA_SHADE_PCT 50u // shade when this share of the live lanes is waiting
+#endif
 #ifndef RT_MEGA_BLOCK
 #define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
 #endif
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         if (!exhausted) {
             const unsigned long long idle_m = __ballot(!live);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            if (cnt >= 16u) {
+            if (cnt >= RT_MEGA_REFILL) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -149,7 +155,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         // TRAVERSE until at least half of the live lanes are waiting for shading
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 2u >= n_live) break;
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live;
             (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
         }
@@ -235,8 +241,14 @@ __global__ void __launch_bounds__(256) k_wf_generate(CameraDev cam, TileDev tile
 // (one atomic per chunk), keeps its 64 lanes fed from the chunk, and writes (t, u, v, tri) to hits[slot].
 // Inside the loop only three uniform step kinds exist: inner node, one triangle, or refill
 // (store finished hits + load new rays) when at least kExtendRefill lanes ask for it.
-constexpr uint32_t kExtendChunk = 128;
-constexpr uint32_t kExtendRefill = 16;
+#ifndef RT_EXTEND_CHUNK
+#define RT_EXTEND_CHUNK 128
+#endif
+#ifndef RT_EXTEND_REFILL
+#define RT_EXTEND_REFILL 16
+#endif
+constexpr uint32_t kExtendChunk = RT_EXTEND_CHUNK;
+constexpr uint32_t kExtendRefill = RT_EXTEND_REFILL;
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 8
 #endif
