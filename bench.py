@@ -8,7 +8,7 @@ are gathered to rank 0 over xGMI and de-interleaved there. Scene, BVH and ray qu
 before the timed region; the frame stays on the device (no PCIe traffic inside the timed region).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (k_wf_shoot) algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
+  roofline     — dominant kernel (k_wf_extend) algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
   cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -26,7 +26,12 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-WAVEFRONT_BYTES_PER_RAY = 76   # 34 B state read + 8 B RNG r/w + 34 B state write
+# Algorithmic bytes per traced ray. SURVEY.md §8(d) prices the reference's single shoot kernel at
+# 76 B/ray (34 B state read + 8 B RNG r/w + 34 B state write). Here that kernel is split in two:
+#   k_wf_extend (dominant, ~78 % of the frame): reads org+id 16 B + dir 8 B, writes the hit record 16 B  = 40 B/ray
+#   k_wf_shade                                : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B = 92 B/ray
+EXTEND_BYTES_PER_RAY = 40
+SHADE_BYTES_PER_RAY = 92
 MEGAKERNEL_BYTES_PER_PIXEL = 20  # one fp32 RGBA store + one RGBA8 store per pixel per frame
 
 
@@ -43,7 +48,8 @@ def main() -> int:
     ap.add_argument("--detail", type=int, default=4, help="atrium tessellation (4 = ~281k triangles)")
     ap.add_argument("--bvh", choices=["sah", "lbvh"], default="sah")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=1, help="samples per pixel of the bounded CPU-oracle sample")
+    ap.add_argument("--no-other-renderer", action="store_true", help="skip the secondary measurement of the other renderer")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the bounded CPU-oracle sample")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,11 +121,30 @@ def main() -> int:
     else:
         rays_all = float(rays)
 
+    other = None
+    if world == 1 and not args.no_other_renderer:
+        # the second renderer of the path on the same frame, same number of steps (reported next to the headline)
+        ocls = MegakernelRenderer if args.renderer == "wavefront" else WavefrontRenderer
+        o = ocls(scene, (W, H), args.depth, args.spp)
+        for _ in range(args.warmup):
+            o.render_frame_device(cam, d_f32=local.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        orays = 0
+        for _ in range(args.steps):
+            orays += o.render_frame_device(cam, d_f32=local.data_ptr()).rays
+        torch.cuda.synchronize()
+        odt = time.perf_counter() - t1
+        other = {"renderer": "megakernel" if args.renderer == "wavefront" else "wavefront",
+                 "value": round(orays / odt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(odt / args.steps * 1e3, 3),
+                 "rays_per_frame": int(orays / args.steps)}
+        o.close()
+
     if rank == 0:
         mrays = rays_all / elapsed / 1e6
         # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch time
         if args.renderer == "wavefront":
-            kernel, bytes_per_launch = "k_wf_shoot", WAVEFRONT_BYTES_PER_RAY * rays / max(hot_launches, 1)
+            kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
         else:
             kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
         mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
@@ -138,6 +163,9 @@ def main() -> int:
                          "note": "incoherent BVH traversal is latency/divergence-bound; HBM fraction is small by construction (DESIGN.md §6)"},
             "device_ms_per_step": round(dev_ms / args.steps, 3),
         }
+        if other:
+            out["other_renderer"] = other
+        out["roofline"]["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY if args.renderer == "wavefront" else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, args.renderer)
         print(json.dumps(out), flush=True)

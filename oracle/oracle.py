@@ -120,6 +120,8 @@ class OracleScene:
         f = np.zeros((rows, W, 4), np.float32)
         b = np.zeros((rows, W, 4), np.uint8)
         rays = C.c_uint64(0)
+        if nthreads <= 0:
+            nthreads = hardware_threads()
         rc = lib().orc_render(self.h, C.byref(cam), kind, seed_mode, max_depth, spp, int(use_bvh), nthreads, rank, world,
                               strip_rows, abi.fptr(f), abi.u8ptr(b), C.byref(rays))
         assert rc == 0
@@ -127,4 +129,25 @@ class OracleScene:
 
 
 def hardware_threads() -> int:
-    return lib().orc_hardware_threads()
+    """Host threads this process may really use: min(hardware threads, CPU affinity, cgroup CPU quota)."""
+    import os
+    n = lib().orc_hardware_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)

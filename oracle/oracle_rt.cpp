@@ -157,7 +157,7 @@ struct Tri {
 struct Box {
     V3 lo, hi;
 };
-struct BNode { // oracle's own BVH (median split); independent of the product's builder
+struct BNode { // oracle's own BVH (sweep SAH on one axis); independent of the product's builder
     Box box;
     int32_t left, right; // children, or left = -1 for a leaf
     uint32_t first, count;
@@ -226,8 +226,9 @@ inline Hit intersect_brute(const Scene& sc, V3 o, V3 d) {
     return best;
 }
 
-// conservative slab test against a padded box (culling only; not part of the spec)
-inline bool slab(const Box& b, V3 o, V3 inv, float tmax) {
+// conservative slab test against a padded box (culling only; not part of the spec). Returns the entry
+// distance, or a negative value when the box is missed.
+inline float slab(const Box& b, V3 o, V3 inv, float tmax) {
     float t0 = (b.lo.x - o.x) * inv.x, t1 = (b.hi.x - o.x) * inv.x;
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
     t0 = (b.lo.y - o.y) * inv.y;
@@ -241,26 +242,35 @@ inline bool slab(const Box& b, V3 o, V3 inv, float tmax) {
     // boxes carry an absolute pad of 1e-4 x scene scale (build_bvh), orders of magnitude above the
     // few-ulp rounding of these products, so the plain comparison cannot cull a true overlap.
     // fminf/fmaxf drop the NaN of 0*inf (ray inside a slab plane with a zero direction component).
-    return tn <= tf && tf >= 0.0f && tn <= tmax;
+    tn = fmaxf(tn, 0.0f);
+    return (tn <= tf && tn <= tmax) ? tn : -1.0f;
 }
 
 inline Hit intersect_bvh(const Scene& sc, V3 o, V3 d) {
     Hit best{std::numeric_limits<float>::infinity(), 0.0f, 0.0f, NO_TRI};
     if (sc.nodes.empty()) return best;
     V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (slab(sc.nodes[0].box, o, inv, best.t) < 0.0f) return best;
     int32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
     while (sp > 0) {
         const BNode& nd = sc.nodes[stack[--sp]];
-        if (!slab(nd.box, o, inv, best.t)) continue;
         if (nd.left < 0) {
             for (uint32_t k = 0; k < nd.count; ++k) {
                 uint32_t ti = sc.order[nd.first + k];
                 mt_hit(sc.tris[ti], ti, o, d, best);
             }
-        } else {
+            continue;
+        }
+        const float tl = slab(sc.nodes[nd.left].box, o, inv, best.t);
+        const float tr = slab(sc.nodes[nd.right].box, o, inv, best.t);
+        if (tl >= 0.0f && tr >= 0.0f) { // nearer child on top of the stack (visited first)
+            if (tl <= tr) stack[sp++] = nd.right, stack[sp++] = nd.left;
+            else stack[sp++] = nd.left, stack[sp++] = nd.right;
+        } else if (tl >= 0.0f) {
             stack[sp++] = nd.left;
+        } else if (tr >= 0.0f) {
             stack[sp++] = nd.right;
         }
     }
@@ -316,15 +326,43 @@ void build_bvh(Scene& sc) {
         nd.count = w.count;
         nd.left = nd.right = -1;
         if (w.count > 4) {
+            // sweep SAH along the axis of largest centroid extent (the oracle's own builder; the image does
+            // not depend on it). Falls back to the median when every candidate is degenerate.
             V3 e = chi - clo;
             int axis = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
-            uint32_t mid = w.count / 2;
             auto key = [&](uint32_t ti) {
                 return axis == 0 ? cent[ti].x : (axis == 1 ? cent[ti].y : cent[ti].z);
             };
-            std::nth_element(sc.order.begin() + w.first, sc.order.begin() + w.first + mid,
-                             sc.order.begin() + w.first + w.count,
-                             [&](uint32_t a, uint32_t b) { return key(a) < key(b) || (key(a) == key(b) && a < b); });
+            std::sort(sc.order.begin() + w.first, sc.order.begin() + w.first + w.count,
+                      [&](uint32_t a, uint32_t b) { return key(a) < key(b) || (key(a) == key(b) && a < b); });
+            auto area = [](V3 l, V3 h) {
+                V3 d = h - l;
+                return d.x * d.y + d.y * d.z + d.z * d.x;
+            };
+            std::vector<float> right_area(w.count);
+            V3 bl = mk(INFINITY, INFINITY, INFINITY), bh = mk(-INFINITY, -INFINITY, -INFINITY);
+            for (uint32_t k = w.count; k-- > 0;) {
+                uint32_t ti = sc.order[w.first + k];
+                for (int j = 0; j < 3; ++j) {
+                    V3 p = sc.wverts[3 * ti + j];
+                    bl = mk(fminf(bl.x, p.x), fminf(bl.y, p.y), fminf(bl.z, p.z));
+                    bh = mk(fmaxf(bh.x, p.x), fmaxf(bh.y, p.y), fmaxf(bh.z, p.z));
+                }
+                right_area[k] = area(bl, bh);
+            }
+            bl = mk(INFINITY, INFINITY, INFINITY), bh = mk(-INFINITY, -INFINITY, -INFINITY);
+            uint32_t mid = w.count / 2;
+            float best_cost = INFINITY;
+            for (uint32_t k = 0; k + 1 < w.count; ++k) {
+                uint32_t ti = sc.order[w.first + k];
+                for (int j = 0; j < 3; ++j) {
+                    V3 p = sc.wverts[3 * ti + j];
+                    bl = mk(fminf(bl.x, p.x), fminf(bl.y, p.y), fminf(bl.z, p.z));
+                    bh = mk(fmaxf(bh.x, p.x), fmaxf(bh.y, p.y), fmaxf(bh.z, p.z));
+                }
+                float cost = area(bl, bh) * (float)(k + 1) + right_area[k + 1] * (float)(w.count - k - 1);
+                if (cost < best_cost) best_cost = cost, mid = k + 1;
+            }
             nd.left = (int32_t)sc.nodes.size();
             nd.right = nd.left + 1;
             sc.nodes.push_back(BNode{});
