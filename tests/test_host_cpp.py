@@ -1,0 +1,174 @@
+"""CPU tests of the C++ host side: GLB loader + texture baker, PNG codec and the
+`raytracer` CLI's argument handling. The GPU half (CLI end to end) is in test_gpu_cli.py."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rtamd import abi, scenes
+from rtamd.glb_export import export_glb
+
+REPO = Path(__file__).resolve().parent.parent
+HOST = REPO / "sycl-ray-tracer_amd" / "host" / "build"
+
+
+@pytest.fixture(scope="module")
+def hostlib(rtlib):
+    p = HOST / "librt_host.so"
+    if not p.exists():
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(str(p))
+    lib.rth_last_error.restype = C.c_char_p
+    lib.rth_load_glb.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.rth_scene_free.argtypes = [C.c_void_p]
+    lib.rth_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.rt_scene_desc)]
+    lib.rth_scene_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.rth_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    lib.rth_decode_png.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_size_t]
+    lib.rth_resize_to_layer.argtypes = [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    return lib
+
+
+class CppScene:
+    """A scene loaded by the C++ loader, viewed as numpy arrays + usable as a SceneDesc for the oracle."""
+
+    def __init__(self, lib, path):
+        self.lib, self.h = lib, C.c_void_p()
+        if lib.rth_load_glb(str(path).encode(), C.byref(self.h)) != 0:
+            raise RuntimeError(lib.rth_last_error().decode())
+        d = abi.rt_scene_desc()
+        lib.rth_scene_desc(self.h, C.byref(d))
+        self.c = d
+        npf = lambda p, n: np.ctypeslib.as_array(p, (n,)).copy() if n else np.zeros(0, np.float32)
+        self.positions = npf(d.positions, 3 * d.n_vertices).reshape(-1, 3)
+        self.normals = npf(d.normals, 3 * d.n_vertices).reshape(-1, 3)
+        self.uvs = npf(d.uvs, 2 * d.n_vertices).reshape(-1, 2)
+        self.indices = np.ctypeslib.as_array(d.indices, (3 * d.n_triangles,)).copy().reshape(-1, 3)
+        self.tri_instance = np.ctypeslib.as_array(d.tri_instance, (d.n_triangles,)).copy()
+        self.instances = [d.instances[i] for i in range(d.n_instances)]
+        self.materials = [d.materials[i] for i in range(d.n_materials)]
+        pos, dr = (C.c_float * 3)(), (C.c_float * 3)()
+        focal, has = C.c_float(), C.c_int()
+        lib.rth_scene_camera(self.h, pos, dr, C.byref(focal), C.byref(has))
+        self.camera = scenes.CameraPose(tuple(pos), tuple(dr), focal.value)
+        self.has_camera = bool(has.value)
+
+    def to_c(self):  # lets oracle.OracleScene consume the C++ loader's arrays directly
+        return self.c
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.rth_scene_free(self.h)
+
+
+@pytest.mark.parametrize("name", ["triangle", "cube"])
+def test_cpp_loader_equals_python_loader_bitwise(hostlib, scene_cache, name):
+    sd = scene_cache(name)
+    cs = CppScene(hostlib, REPO / "assets" / f"{name}.glb")
+    np.testing.assert_array_equal(cs.positions, sd.positions)
+    np.testing.assert_array_equal(cs.normals, sd.normals)
+    np.testing.assert_array_equal(cs.uvs, sd.uvs)
+    np.testing.assert_array_equal(cs.indices, sd.indices)
+    np.testing.assert_array_equal(cs.tri_instance, sd.tri_instance)
+    py = sd.to_c()
+    assert cs.c.n_instances == py.n_instances and cs.c.n_materials == py.n_materials and cs.c.n_layers == 0
+    for i in range(py.n_instances):
+        assert bytes(cs.instances[i]) == bytes(py.instances[i])
+    for i in range(py.n_materials):
+        assert bytes(cs.materials[i]) == bytes(py.materials[i])
+    assert list(cs.c.sky) == list(py.sky)
+    assert not cs.has_camera  # neither shipped asset has one: documented defaults apply
+    np.testing.assert_allclose(cs.camera.position, sd.camera.position, rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(np.float32(cs.camera.direction), np.float32(sd.camera.direction))
+
+
+@pytest.mark.parametrize("name,kw,w,h", [("cornell", {}, 40, 40), ("atrium", {"detail": 1}, 48, 27)])
+def test_exported_glb_renders_identically_through_the_cpp_loader(hostlib, oracle, scene_cache, tmp_path, name, kw, w, h):
+    """generator -> GLB (instancing, rotations, emissive/ior extensions, PNG textures, sky extras, camera node)
+    -> C++ loader: the oracle renders the same image from both descriptions."""
+    sd = scene_cache(name, **kw)
+    path = tmp_path / f"{name}.glb"
+    export_glb(sd, path)
+    cs = CppScene(hostlib, path)
+    assert cs.c.n_triangles == sd.n_triangles and cs.c.n_layers == sd.textures.shape[0]
+    if sd.textures.shape[0]:
+        tex = np.ctypeslib.as_array(cs.c.textures, (cs.c.n_layers, 512, 512, 4))
+        np.testing.assert_array_equal(tex, sd.textures)  # 512x512 PNGs are baked without resampling
+    assert cs.has_camera
+    np.testing.assert_allclose(cs.camera.position, np.float32(sd.camera.position), atol=1e-6)
+    dn = np.array(sd.camera.direction) / np.linalg.norm(sd.camera.direction)
+    np.testing.assert_allclose(cs.camera.direction, dn, atol=1e-6)
+    np.testing.assert_allclose(cs.camera.focal_length, sd.camera.focal_length, rtol=1e-6)
+    cam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    a = oracle.OracleScene(sd).render(cam, 0, 6, 2)
+    b = oracle.OracleScene(cs).render(cam, 0, 6, 2)
+    assert a[2] == b[2]
+    np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_loader_error_paths(hostlib, tmp_path):
+    h = C.c_void_p()
+    assert hostlib.rth_load_glb(str(tmp_path / "missing.glb").encode(), C.byref(h)) != 0
+    assert b"cannot open" in hostlib.rth_last_error()
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"not a glb file at all.....")
+    assert hostlib.rth_load_glb(str(bad).encode(), C.byref(h)) != 0
+    assert b"GLB" in hostlib.rth_last_error()
+    trunc = tmp_path / "trunc.glb"
+    trunc.write_bytes((REPO / "assets" / "cube.glb").read_bytes()[:600])
+    assert hostlib.rth_load_glb(str(trunc).encode(), C.byref(h)) != 0
+
+
+def test_png_codec_against_pil(hostlib, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    assert hostlib.rth_write_png(str(path).encode(), 53, 37, abi.u8ptr(np.ascontiguousarray(img))) == 0
+    np.testing.assert_array_equal(np.asarray(Image.open(path).convert("RGBA")), img)  # our encoder, PIL's decoder
+    for mode, ref in (("RGBA", img), ("RGB", img[..., :3]), ("L", img[..., 0]), ("P", None), ("LA", img[..., [0, 3]])):
+        p = tmp_path / f"m_{mode}.png"
+        pil = Image.fromarray(img, "RGBA").convert(mode) if mode != "LA" else Image.fromarray(np.ascontiguousarray(ref), "LA")
+        pil.save(p)
+        data = np.frombuffer(p.read_bytes(), np.uint8)
+        w, h = C.c_uint32(), C.c_uint32()
+        out = np.zeros((37, 53, 4), np.uint8)
+        assert hostlib.rth_decode_png(abi.u8ptr(data), data.size, C.byref(w), C.byref(h), abi.u8ptr(out), out.size) == 0, \
+            hostlib.rth_last_error()
+        assert (w.value, h.value) == (53, 37)
+        np.testing.assert_array_equal(out, np.asarray(pil.convert("RGBA")))  # PIL's encoder, our decoder
+
+
+def test_texture_resize_semantics(hostlib):
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, (512, 512, 4), dtype=np.uint8)
+    out = np.zeros_like(src)
+    hostlib.rth_resize_to_layer(abi.u8ptr(src), 512, 512, abi.u8ptr(out))
+    np.testing.assert_array_equal(out, src)  # 512x512 passes through untouched
+    flat = np.full((64, 32, 4), (200, 100, 50, 255), np.uint8)
+    hostlib.rth_resize_to_layer(abi.u8ptr(flat), 32, 64, abi.u8ptr(out))
+    assert (out == np.array([200, 100, 50, 255], np.uint8)).all()  # constant images stay constant (up-sampling)
+    big = np.zeros((1024, 1024, 4), np.uint8)
+    big[..., 3] = 255
+    big[:, 512:, :3] = 255
+    hostlib.rth_resize_to_layer(abi.u8ptr(big), 1024, 1024, abi.u8ptr(out))
+    assert (out[:, :255, :3] == 0).all() and (out[:, 257:, :3] == 255).all()  # 2x2 box average keeps the edge sharp
+
+
+def test_cli_flags_match_the_reference(rtlib):
+    exe = HOST / "raytracer"
+    assert exe.exists()
+    out = subprocess.run([str(exe), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("-d,--max-depth", "-s,--sample-count", "-w,--wavefront", "-m,--megakernel", "scene_path"):
+        assert flag in out.stdout
+    bad = subprocess.run([str(exe), "--nope"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "not expected" in bad.stderr
+    bad = subprocess.run([str(exe), "-d", "abc"], capture_output=True, text=True)
+    assert bad.returncode != 0
+    if rtlib.rt_device_count() <= 0:  # no GPU here: the CLI must fail loudly, not fall back
+        r = subprocess.run([str(exe), "-s", "1", str(REPO / "assets" / "cube.glb")], capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stdout
