@@ -390,16 +390,21 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 }
 
 // ---- K6 + K7: mean over samples, sqrt gamma, fp32 + unorm8 outputs ------------------------------------
-__global__ void __launch_bounds__(256) k_wf_resolve(uint32_t n_local, uint32_t spp, const float4* __restrict__ accum,
+__global__ void __launch_bounds__(256) k_wf_resolve(uint32_t n_local, uint32_t spp, uint32_t width, uint32_t strip_rows,
+                                                     uint32_t n_lanes, uint32_t lane_index, const float4* __restrict__ accum,
                                                      float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_local) return;
     const float4 a = accum[i];
     const float n = (float)spp;
     const f3 c = mk3(__builtin_sqrtf(a.x / n), __builtin_sqrtf(a.y / n), __builtin_sqrtf(a.z / n));
-    if (out_f32) reinterpret_cast<float4*>(out_f32)[i] = make_float4(c.x, c.y, c.z, 1.0f);
+    // row r of stream-lane `lane_index` (its strips are every n_lanes-th strip of the renderer's tile) -> tile row
+    const uint32_t x = i % width, r = i / width;
+    const uint32_t row = ((r / strip_rows) * n_lanes + lane_index) * strip_rows + r % strip_rows;
+    const size_t o = (size_t)row * width + x;
+    if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
     if (out_u8)
-        reinterpret_cast<uint32_t*>(out_u8)[i] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+        reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
                                                  ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
 }
 
