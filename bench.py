@@ -165,7 +165,18 @@ def main() -> int:
         }
         if other:
             out["other_renderer"] = other
-        out["roofline"]["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY if args.renderer == "wavefront" else None
+        if args.renderer == "wavefront":
+            frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
+            out["roofline"]["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
+            out["roofline"]["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
+            out["roofline"]["concurrent_streams"] = 2  # two sub-tiles run on two streams: a launch shares the chip with its twin
+        traffic_file = REPO / "profiles" / "r01_traffic.json"
+        if traffic_file.exists():  # PMC-measured fabric traffic of the same kernels (rocprofv3 cannot run inside bench.py)
+            t = json.loads(traffic_file.read_text()).get(kernel)
+            if t and (args.width, args.height) == (1920, 1080) and world == 1:
+                out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"], 1)
+                out["roofline"]["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_traffic.json (separate rocprofv3 --pmc passes, "
+                                                   "1080p, same launch sizes); mostly BVH/triangle gathers served by the Infinity Cache")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, args.renderer)
         print(json.dumps(out), flush=True)
