@@ -117,7 +117,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
-    bool exhausted = false; // wave-uniform: the pixel cursor has passed the last slot
+    bool exhausted = false; // wave-uniform: every region's cursor has passed its last slot
+    const uint32_t region_slots = ((n_slots + 7u) / 8u + 63u) & ~63u;
+    uint32_t region = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID[3:0]
+    uint32_t regions_done = 0;
     for (;;) {
         // REFILL: idle lanes take the next pixels from the frame-wide cursor, one atomic per wave and round.
         // A wave is persistent: it keeps pulling pixels until the frame is exhausted, so a lane whose
@@ -126,11 +129,16 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             const unsigned long long idle_m = __ballot(!live);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
             if (cnt >= RT_MEGA_REFILL) {
+                // The frame's pixel slots are cut into 8 contiguous regions, one per XCD: a wave first drains the
+                // region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others. Waves that share an
+                // L2 thus work on one part of the picture, i.e. on the same part of the scene (speed only: any
+                // placement gives the same image).
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
+                if (lane == 0) base = atomicAdd(pixel_cursor + region, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                if (!live && p < n_slots) {
+                const uint32_t rel = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const uint32_t p = region * region_slots + rel;
+                if (!live && rel < region_slots && p < n_slots) {
                     const uint32_t t = p >> 6;
                     x = (int)((t % tiles_x) * 8u + (p & 7u));
                     ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
@@ -144,7 +152,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                         live = true;
                     }
                 }
-                exhausted = base + cnt >= n_slots;
+                if (base + cnt >= region_slots) { // this region is used up: move on to the next one
+                    region = (region + 1u) & 7u;
+                    exhausted = ++regions_done >= 8u;
+                }
             }
         }
         const uint32_t n_live = (uint32_t)__popcll(__ballot(live));

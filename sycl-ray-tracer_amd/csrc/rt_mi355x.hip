@@ -142,7 +142,7 @@ int alloc_tile_buffers(rt_renderer* r) {
     HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
     HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 2 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors
     } else {
         uint32_t K = 2;
         if (const char* e = std::getenv("RT_WF_STREAMS")) K = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
@@ -202,7 +202,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         return RT_OK;
     }
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 2 * sizeof(unsigned long long), st)); // ray count + pixel cursor
+        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 8 * sizeof(unsigned long long), st)); // ray count + region cursors
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
         constexpr uint32_t mega_wpb = RT_MEGA_BLOCK / 64;

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <deque>
@@ -150,6 +151,9 @@ void build_lbvh(Builder& b) {
 void build_sah(Builder& b, uint32_t max_sah_depth) {
     const uint32_t n = (uint32_t)b.order.size();
     constexpr int NB = 32;
+    // cost of one traversal step relative to one triangle test, for the leaf-vs-split decision of small ranges
+    float trav_cost = 1.0f;
+    if (const char* e = std::getenv("RT_SAH_TRAV_COST")) trav_cost = (float)std::atof(e);
     struct Work {
         int32_t node;
         uint32_t first, count, depth;
@@ -212,7 +216,7 @@ void build_sah(Builder& b, uint32_t max_sah_depth) {
             }
             // leaf cost = count * area; split cost = 1 traversal step * area + children
             if (w.count <= (uint32_t)kMaxLeafTris &&
-                !(best_axis >= 0 && best_cost + 1.0f * parent_area < (float)w.count * parent_area)) {
+                !(best_axis >= 0 && best_cost + trav_cost * parent_area < (float)w.count * parent_area)) {
                 make_leaf = true;
             } else if (best_axis >= 0) {
                 float ext = chi[best_axis] - clo[best_axis];
