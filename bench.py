@@ -7,8 +7,11 @@ k with k % N == r of the SAME frame (strong scaling: total work is fixed), then 
 are gathered to rank 0 over xGMI and de-interleaved there. Scene, BVH and ray queues are resident in HBM
 before the timed region; the frame stays on the device (no PCIe traffic inside the timed region).
 
+Both renderers of the path (wavefront, megakernel) are measured with the same K steps; the headline `value` is the
+faster one (`config.renderer`), `renderers` holds both with their rooflines.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (k_wf_extend) algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
+  roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
   cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -40,7 +43,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--renderer", choices=["wavefront", "megakernel"], default=os.environ.get("RT_BENCH_RENDERER", "wavefront"))
+    ap.add_argument("--renderer", choices=["auto", "wavefront", "megakernel"], default=os.environ.get("RT_BENCH_RENDERER", "auto"),
+                    help="auto = measure both renderers of the path, headline the faster one")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
@@ -48,8 +52,7 @@ def main() -> int:
     ap.add_argument("--detail", type=int, default=4, help="atrium tessellation (4 = ~281k triangles)")
     ap.add_argument("--bvh", choices=["sah", "lbvh"], default="sah")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-renderer", action="store_true", help="skip the secondary measurement of the other renderer")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,112 +78,101 @@ def main() -> int:
     sd = scenes.atrium_scene(args.detail)
     scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
     cam = Camera.for_scene(sd, (W, H))
-    cls = WavefrontRenderer if args.renderer == "wavefront" else MegakernelRenderer
-    r = cls(scene, (W, H), args.depth, args.spp)
-    r.set_tile(rank, world, strip)
-    r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the render stream
-    rows = r.local_rows
     from rtamd.dist import FrameGatherer
     fg = FrameGatherer(rank, world, W, H, strip, dev)
-    assert fg.rows == rows
     local = fg.local
-
-    def step():
-        fr = r.render_frame_device(cam, d_f32=local.data_ptr())
-        fg.gather()  # RCCL gather of the per-GPU strip buffers + de-interleave on rank 0
-        return fr
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    rays = 0
-    hot_ms, hot_launches, dev_ms = 0.0, 0, 0.0
-    for _ in range(args.steps):
-        fr = step()
-        rays += fr.rays
-        hot_ms += fr.hot_kernel_ms
-        hot_launches += fr.hot_kernel_launches
-        dev_ms += fr.device_ms
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def measure(name):
+        """W warm-up frames, then exactly K timed frames of one renderer: render this rank's strips, RCCL gather,
+        de-interleave on rank 0; barrier + synchronize on both sides; MAX over ranks of the time, SUM of the rays."""
+        cls = WavefrontRenderer if name == "wavefront" else MegakernelRenderer
+        r = cls(scene, (W, H), args.depth, args.spp)
+        r.set_tile(rank, world, strip)
+        r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the launch's own stream
+        assert fg.rows == r.local_rows
 
-    tot = torch.tensor([elapsed, float(rays), hot_ms, float(hot_launches)], dtype=torch.float64, device=dev)
-    if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        rays_all = float(sm[1])
-    else:
-        rays_all = float(rays)
+        def step():
+            fr = r.render_frame_device(cam, d_f32=local.data_ptr())
+            fg.gather()  # RCCL gather of the per-GPU strip buffers + de-interleave on rank 0
+            return fr
 
-    other = None
-    if world == 1 and not args.no_other_renderer:
-        # the second renderer of the path on the same frame, same number of steps (reported next to the headline)
-        ocls = MegakernelRenderer if args.renderer == "wavefront" else WavefrontRenderer
-        o = ocls(scene, (W, H), args.depth, args.spp)
         for _ in range(args.warmup):
-            o.render_frame_device(cam, d_f32=local.data_ptr())
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        orays = 0
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        rays, hot_ms, hot_launches, dev_ms = 0, 0.0, 0, 0.0
         for _ in range(args.steps):
-            orays += o.render_frame_device(cam, d_f32=local.data_ptr()).rays
-        torch.cuda.synchronize()
-        odt = time.perf_counter() - t1
-        other = {"renderer": "megakernel" if args.renderer == "wavefront" else "wavefront",
-                 "value": round(orays / odt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(odt / args.steps * 1e3, 3),
-                 "rays_per_frame": int(orays / args.steps)}
-        o.close()
-
-    if rank == 0:
-        mrays = rays_all / elapsed / 1e6
+            fr = step()
+            rays += fr.rays
+            hot_ms += fr.hot_kernel_ms
+            hot_launches += fr.hot_kernel_launches
+            dev_ms += fr.device_ms
+        barrier()
+        elapsed = time.perf_counter() - t0
+        rows = r.local_rows
+        r.close()
+        rays_all = float(rays)
+        if world > 1:
+            mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            elapsed, rays_all = float(mx[0]), float(sm[0])
         # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch time
-        if args.renderer == "wavefront":
+        if name == "wavefront":
             kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
         else:
             kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
         mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
         achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": hot_launches,
+                "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1)}
+        if name == "wavefront":
+            frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
+            roof["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
+            roof["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
+            roof["concurrent_streams"] = 2  # two sub-tiles on two streams: a launch shares the chip with its twin
+            roof["note"] = "incoherent BVH traversal is bound by gather latency and VALU issue; the HBM fraction is small by construction (DESIGN.md §6)"
+        else:
+            roof["note"] = ("the megakernel has no per-ray HBM stream (SURVEY.md §8d): its only algorithmic HBM traffic is the frame store; "
+                            "its BVH gathers are served by L2 / Infinity Cache (profiles/r01_traffic.json)")
+        traffic_file = REPO / "profiles" / "r01_traffic.json"
+        if traffic_file.exists() and (W, H) == (1920, 1080) and world == 1:
+            t = json.loads(traffic_file.read_text()).get(kernel)  # PMC-measured (rocprofv3 cannot run inside bench.py)
+            if t:
+                scale = args.spp / 4.0 if name == "megakernel" else 1.0  # the megakernel profile is a 4-spp frame
+                roof["traffic"] = round(t["traffic_bytes_per_launch"] * scale, 1)
+                roof["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_traffic.json (separate rocprofv3 --pmc passes at "
+                                        "1080p); mostly BVH/triangle gathers served by the Infinity Cache, not re-reads of the ray stream")
+        return {"renderer": name, "value": round(rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "rays_per_frame": int(rays_all / args.steps),
+                "device_ms_per_step": round(dev_ms / args.steps, 3), "roofline": roof}
+
+    names = ["wavefront", "megakernel"] if args.renderer == "auto" else [args.renderer]
+    results = [measure(n) for n in names]
+
+    if rank == 0:
+        best = max(results, key=lambda d: d["value"])  # headline: the faster of the path's two renderers
         out = {
-            "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "metric": "Mrays/s", "value": best["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": best["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}",
-                       "renderer": args.renderer, "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}",
-                       "rays_per_frame": int(rays_all / args.steps)},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "launches": hot_launches, "mean_launch_ms": round(mean_launch_s * 1e3, 5),
-                         "bytes_per_launch": round(bytes_per_launch, 1),
-                         "note": "incoherent BVH traversal is latency/divergence-bound; HBM fraction is small by construction (DESIGN.md §6)"},
-            "device_ms_per_step": round(dev_ms / args.steps, 3),
+                       "renderer": best["renderer"], "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}",
+                       "rays_per_frame": best["rays_per_frame"]},
+            "roofline": best["roofline"],
+            "device_ms_per_step": best["device_ms_per_step"],
+            "renderers": {d["renderer"]: d for d in results},
         }
-        if other:
-            out["other_renderer"] = other
-        if args.renderer == "wavefront":
-            frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
-            out["roofline"]["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
-            out["roofline"]["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
-            out["roofline"]["concurrent_streams"] = 2  # two sub-tiles run on two streams: a launch shares the chip with its twin
-        traffic_file = REPO / "profiles" / "r01_traffic.json"
-        if traffic_file.exists():  # PMC-measured fabric traffic of the same kernels (rocprofv3 cannot run inside bench.py)
-            t = json.loads(traffic_file.read_text()).get(kernel)
-            if t and (args.width, args.height) == (1920, 1080) and world == 1:
-                out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"], 1)
-                out["roofline"]["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_traffic.json (separate rocprofv3 --pmc passes, "
-                                                   "1080p, same launch sizes); mostly BVH/triangle gathers served by the Infinity Cache")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, args.renderer)
+            out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
         print(json.dumps(out), flush=True)
-    r.close()
     scene.close()
     if world > 1:
         dist.destroy_process_group()
