@@ -334,7 +334,11 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
     const bool inner = T.cur >= 0;
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
-    if (ni >= nl) {
+#ifndef RT_LEAF_NUM
+#define RT_LEAF_NUM 1u
+#define RT_LEAF_DEN 1u
+#endif
+    if (ni * RT_LEAF_NUM >= nl * RT_LEAF_DEN) {
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes));
         if (inner) trav_inner(S, T, stack, top);
     } else {
