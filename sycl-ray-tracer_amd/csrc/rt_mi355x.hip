@@ -46,6 +46,20 @@ int device_ok(int device) {
     return RT_OK;
 }
 
+// device allocation that frees itself on every return path of the C entry points
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
 template <typename T>
 int upload(const std::vector<T>& v, const T** out, uint64_t& bytes) {
     *out = nullptr;
@@ -493,10 +507,11 @@ int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* d
     if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
     if (n == 0) return RT_OK;
     HIPCHK(hipSetDevice(s->device));
-    float *d_org = nullptr, *d_dir = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_org, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_dir, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 16));
+    DevBuf b_org, b_dir, b_out;
+    HIPCHK(b_org.alloc((size_t)n * 12));
+    HIPCHK(b_dir.alloc((size_t)n * 12));
+    HIPCHK(b_out.alloc((size_t)n * 16));
+    float *d_org = b_org.as<float>(), *d_dir = b_dir.as<float>(), *d_out = b_out.as<float>();
     HIPCHK(hipMemcpy(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
     float* d_t = d_out;
@@ -510,7 +525,6 @@ int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* d
     HIPCHK(hipMemcpy(u, d_u, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(v, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_org), (void)hipFree(d_dir), (void)hipFree(d_out);
     return RT_OK;
 }
 
@@ -607,16 +621,14 @@ int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_
     if (!out || !state_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
     int rc = device_ok(device);
     if (rc != RT_OK) return rc;
-    float* d_out = nullptr;
-    uint32_t* d_st = nullptr;
-    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMalloc((void**)&d_st, 4));
-    hipLaunchKernelGGL(k_probe_xorshift, dim3(1), dim3(64), 0, 0, seed, n, d_out, d_st);
+    DevBuf b_out, b_st;
+    HIPCHK(b_out.alloc((size_t)n * 4));
+    HIPCHK(b_st.alloc(4));
+    hipLaunchKernelGGL(k_probe_xorshift, dim3(1), dim3(64), 0, 0, seed, n, b_out.as<float>(), b_st.as<uint32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(state_out, d_st, 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_out), (void)hipFree(d_st);
+    HIPCHK(hipMemcpy(out, b_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(state_out, b_st.p, 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -624,18 +636,16 @@ int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out,
     if (!in || !out || !bits_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
     int rc = device_ok(device);
     if (rc != RT_OK) return rc;
-    float *d_in = nullptr, *d_out = nullptr;
-    uint16_t* d_bits = nullptr;
-    HIPCHK(hipMalloc((void**)&d_in, (size_t)n * 4));
-    HIPCHK(hipMalloc((void**)&d_out, (size_t)n * 4));
-    HIPCHK(hipMalloc((void**)&d_bits, (size_t)n * 2));
-    HIPCHK(hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_half, dim3((n + 255u) / 256u), dim3(256), 0, 0, n, d_in, d_out, d_bits);
+    DevBuf b_in, b_out, b_bits;
+    HIPCHK(b_in.alloc((size_t)n * 4));
+    HIPCHK(b_out.alloc((size_t)n * 4));
+    HIPCHK(b_bits.alloc((size_t)n * 2));
+    HIPCHK(hipMemcpy(b_in.p, in, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_half, dim3((n + 255u) / 256u), dim3(256), 0, 0, n, b_in.as<float>(), b_out.as<float>(), b_bits.as<uint16_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(bits_out, d_bits, (size_t)n * 2, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_bits);
+    HIPCHK(hipMemcpy(out, b_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bits_out, b_bits.p, (size_t)n * 2, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -646,31 +656,28 @@ int rt_probe_scatter(rt_scene* s, uint32_t material, uint32_t n, const float* di
     if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
     if (material >= s->hs.mats.size()) return fail(RT_ERR_INVALID, "material index out of range");
     HIPCHK(hipSetDevice(s->device));
-    float *d_dir, *d_nrm, *d_uv, *d_od, *d_oa;
-    uint32_t *d_seed, *d_so;
-    uint8_t* d_ok;
-    HIPCHK(hipMalloc((void**)&d_dir, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_nrm, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_uv, (size_t)n * 8));
-    HIPCHK(hipMalloc((void**)&d_od, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_oa, (size_t)n * 12));
-    HIPCHK(hipMalloc((void**)&d_seed, (size_t)n * 4));
-    HIPCHK(hipMalloc((void**)&d_so, (size_t)n * 4));
-    HIPCHK(hipMalloc((void**)&d_ok, (size_t)n));
-    HIPCHK(hipMemcpy(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_nrm, normal, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_uv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_seed, seed, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_scatter, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, material, n, d_dir, d_nrm, d_uv,
-                       d_seed, d_ok, d_od, d_oa, d_so);
+    DevBuf b_dir, b_nrm, b_uv, b_od, b_oa, b_seed, b_so, b_ok;
+    HIPCHK(b_dir.alloc((size_t)n * 12));
+    HIPCHK(b_nrm.alloc((size_t)n * 12));
+    HIPCHK(b_uv.alloc((size_t)n * 8));
+    HIPCHK(b_od.alloc((size_t)n * 12));
+    HIPCHK(b_oa.alloc((size_t)n * 12));
+    HIPCHK(b_seed.alloc((size_t)n * 4));
+    HIPCHK(b_so.alloc((size_t)n * 4));
+    HIPCHK(b_ok.alloc((size_t)n));
+    HIPCHK(hipMemcpy(b_dir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b_nrm.p, normal, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b_uv.p, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b_seed.p, seed, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_scatter, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, material, n, b_dir.as<float>(),
+                       b_nrm.as<float>(), b_uv.as<float>(), b_seed.as<uint32_t>(), b_ok.as<uint8_t>(), b_od.as<float>(),
+                       b_oa.as<float>(), b_so.as<uint32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_dir, d_od, (size_t)n * 12, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_att, d_oa, (size_t)n * 12, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(seed_out, d_so, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_dir), (void)hipFree(d_nrm), (void)hipFree(d_uv), (void)hipFree(d_od), (void)hipFree(d_oa);
-    (void)hipFree(d_seed), (void)hipFree(d_so), (void)hipFree(d_ok);
+    HIPCHK(hipMemcpy(ok, b_ok.p, (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_dir, b_od.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_att, b_oa.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(seed_out, b_so.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
