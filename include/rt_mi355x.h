@@ -108,7 +108,11 @@ typedef struct rt_scene rt_scene;       /* opaque: device-resident flattened tri
 typedef struct rt_renderer rt_renderer; /* opaque: ray queues, RNG states, accumulators      */
 
 /* BVH builder selection for rt_scene_create (the image is independent of the choice). */
-enum { RT_BVH_DEFAULT = 0, RT_BVH_LBVH = 1, RT_BVH_SAH = 2 };
+/*   RT_BVH_SAH      binned surface-area heuristic, built on the host (default: fastest traversal)
+ *   RT_BVH_LBVH     Morton-order LBVH, built on the host
+ *   RT_BVH_LBVH_GPU the same LBVH family built entirely on the device (Morton codes, radix sort, Karras tree,
+ *                   refit, BVH4 collapse + quantisation): fastest build, needs device >= 0 */
+enum { RT_BVH_DEFAULT = 0, RT_BVH_LBVH = 1, RT_BVH_SAH = 2, RT_BVH_LBVH_GPU = 3 };
 
 /* Builds the world-space triangle set and the BVH, uploads everything to HIP device `device`.
  * Replaces Scene's Embree side: rtcNewScene/rtcAttachGeometry/rtcCommitScene

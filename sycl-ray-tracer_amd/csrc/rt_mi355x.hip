@@ -436,8 +436,13 @@ int rt_camera_init(rt_camera* out, int32_t width, int32_t height, const float ce
 int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "null output pointer");
     *out = nullptr;
-    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH)
+    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH && bvh_kind != RT_BVH_LBVH_GPU)
         return fail(RT_ERR_INVALID, "unknown bvh_kind");
+    if (bvh_kind == RT_BVH_LBVH_GPU) { // the build itself runs on the device
+        if (device < 0) return fail(RT_ERR_NO_DEVICE, "RT_BVH_LBVH_GPU needs a device (device >= 0)");
+        int rc0 = device_ok(device);
+        if (rc0 != RT_OK) return rc0;
+    }
     rt_scene* s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ERR_OOM, "host allocation failed");
     std::string err;

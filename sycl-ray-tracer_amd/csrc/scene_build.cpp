@@ -313,7 +313,8 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     if (d->n_layers > RT_TEX_MAX_LAYERS) { err = "more than 128 texture layers"; return RT_ERR_INVALID; }
     if (d->n_layers && !d->textures) { err = "null texture array"; return RT_ERR_INVALID; }
     if (d->n_triangles >= (1u << 28)) { err = "too many triangles (limit 2^28)"; return RT_ERR_INVALID; }
-    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH && bvh_kind != RT_BVH_MEDIAN_INTERNAL) {
+    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH && bvh_kind != RT_BVH_MEDIAN_INTERNAL &&
+        bvh_kind != RT_BVH_LBVH_GPU) {
         err = "unknown bvh_kind"; return RT_ERR_INVALID;
     }
     for (uint32_t i = 0; i < d->n_instances; ++i) {
@@ -400,21 +401,43 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         return RT_OK;
     }
 
-    Builder b(hs.wverts);
-    if (bvh_kind == RT_BVH_LBVH) build_lbvh(b);
-    else build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
-
-    const GNode& g0 = b.nodes[0];
-    for (int a = 0; a < 3; ++a) hs.bounds_lo[a] = g0.lo[a], hs.bounds_hi[a] = g0.hi[a];
+    for (int a = 0; a < 3; ++a) hs.bounds_lo[a] = INFINITY, hs.bounds_hi[a] = -INFINITY;
+    for (size_t i = 0; i < hs.wverts.size(); ++i) {
+        const int a = (int)(i % 3);
+        hs.bounds_lo[a] = std::min(hs.bounds_lo[a], hs.wverts[i]), hs.bounds_hi[a] = std::max(hs.bounds_hi[a], hs.wverts[i]);
+    }
     float ext = 0.0f, amax = 0.0f;
     for (int a = 0; a < 3; ++a) {
-        ext = std::max(ext, g0.hi[a] - g0.lo[a]);
-        amax = std::max(amax, std::max(std::fabs(g0.lo[a]), std::fabs(g0.hi[a])));
+        ext = std::max(ext, hs.bounds_hi[a] - hs.bounds_lo[a]);
+        amax = std::max(amax, std::max(std::fabs(hs.bounds_lo[a]), std::fabs(hs.bounds_hi[a])));
     }
     // Absolute padding of every box: 2e-5 x scene scale. Float rounding of the slab test and of the
     // Moller-Trumbore t is ~1e-7 x scale, so a padded box can only cull triangles the exact test
     // would also miss ("culling is conservative").
     hs.pad = 2e-5f * std::max(ext, amax) + 1e-30f;
+
+    // Exact worst-case traversal stack need: at every level all siblings of the entered child may be waiting.
+    std::function<uint32_t(int32_t)> need = [&](int32_t node) -> uint32_t {
+        const BvhNode& n = hs.nodes[node];
+        uint32_t nk = 0, worst = 0;
+        for (int k = 0; k < 4; ++k) nk += n.child[k] != kChildEmpty;
+        for (int k = 0; k < 4; ++k)
+            if (n.child[k] != kChildEmpty) worst = std::max(worst, (nk - 1) + (n.child[k] >= 0 ? need(n.child[k]) : 0u));
+        return worst;
+    };
+
+    if (bvh_kind == RT_BVH_LBVH_GPU && T >= 8) { // whole build on the device (lbvh_gpu.hip); tiny scenes use the host
+        int rc = build_lbvh_gpu(hs, gtris, err);
+        if (rc != RT_OK) return rc;
+        hs.stack_need = need(0);
+        if (hs.stack_need + 1 < (uint32_t)kStackSize) return RT_OK;
+        return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // degenerate Morton order: balanced host fallback
+    }
+
+    Builder b(hs.wverts);
+    if (bvh_kind == RT_BVH_LBVH || bvh_kind == RT_BVH_LBVH_GPU) build_lbvh(b);
+    else build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
+    const GNode& g0 = b.nodes[0];
 
     // Collapse the binary tree into a 4-wide one (repeatedly open the inner child with the largest
     // surface area) and emit it breadth-first: the top levels are contiguous in memory.
@@ -498,15 +521,6 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     }
     hs.sah_cost = cost;
     if (hs.tris.size() != T) { err = "internal: triangle count mismatch after build"; return RT_ERR_INVALID; }
-    // Exact worst-case traversal stack need: at every level all siblings of the entered child may be waiting.
-    std::function<uint32_t(int32_t)> need = [&](int32_t node) -> uint32_t {
-        const BvhNode& n = hs.nodes[node];
-        uint32_t nk = 0, worst = 0;
-        for (int k = 0; k < 4; ++k) nk += n.child[k] != kChildEmpty;
-        for (int k = 0; k < 4; ++k)
-            if (n.child[k] != kChildEmpty) worst = std::max(worst, (nk - 1) + (n.child[k] >= 0 ? need(n.child[k]) : 0u));
-        return worst;
-    };
     hs.stack_need = need(0);
     if (hs.stack_need + 1 >= (uint32_t)kStackSize) {
         if (bvh_kind != RT_BVH_MEDIAN_INTERNAL) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // balanced fallback

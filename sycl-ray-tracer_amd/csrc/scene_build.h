@@ -31,6 +31,9 @@ constexpr int RT_BVH_MEDIAN_INTERNAL = 99; // balanced fallback when a tree woul
 // Validates `desc` and fills `out`. Returns RT_OK or RT_ERR_INVALID with `err` set.
 int build_host_scene(const rt_scene_desc* desc, int bvh_kind, HostScene& out, std::string& err);
 
+// lbvh_gpu.hip: BVH construction on the current HIP device; fills hs.nodes / hs.tris (downloaded copies).
+int build_lbvh_gpu(HostScene& hs, const std::vector<TriRec>& gtris, std::string& err);
+
 // Structural check used by rt_scene_check_bvh.
 int check_bvh(const HostScene& hs, std::string& err);
 

@@ -20,7 +20,7 @@ RT_MAT_NONE, RT_MAT_DIFFUSE, RT_MAT_METALLIC, RT_MAT_DIELECTRIC = 0, 1, 2, 3
 RT_TEX_COLOR, RT_TEX_IMAGE = 0, 1
 RT_RENDERER_MEGAKERNEL, RT_RENDERER_WAVEFRONT = 0, 1
 RT_SEED_DEFAULT, RT_SEED_WAVEFRONT, RT_SEED_MEGAKERNEL = 0, 1, 2
-RT_BVH_DEFAULT, RT_BVH_LBVH, RT_BVH_SAH = 0, 1, 2
+RT_BVH_DEFAULT, RT_BVH_LBVH, RT_BVH_SAH, RT_BVH_LBVH_GPU = 0, 1, 2, 3
 RT_TEX_SIZE = 512
 RT_TEX_MAX_LAYERS = 128
 

@@ -109,7 +109,7 @@ def test_device_scatter_all_materials(gpu_scenes, oracle, scene_cache):
 
 @pytest.mark.parametrize("name,kw,brute", [("triangle", {}, True), ("cube", {}, True), ("cornell", {}, True),
                                             ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False)])
-@pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH])
+@pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH, abi.RT_BVH_LBVH_GPU])
 def test_intersect_batch_equals_oracle(gpu_scenes, oracle, scene_cache, name, kw, brute, bvh):
     """rtcIntersect1 replacement: BVH traversal on the GPU == brute force over all triangles on the CPU,
     for camera rays, random interior rays and rays that start ON surfaces (the self-hit / tnear case)."""
@@ -208,16 +208,39 @@ def test_megakernel_equals_wavefront_with_equal_seeds(gpu_scenes, seed_mode):
         a.close(), b.close()
 
 
+def test_gpu_built_lbvh_is_valid_and_fast(gpu_scenes, scene_cache):
+    """RT_BVH_LBVH_GPU: Morton + radix sort + Karras + refit + BVH4 collapse on the device. The downloaded tree
+    passes the host's structural check; the build beats the host SAH build."""
+    import time
+    sd = scene_cache("atrium", detail=4)
+    t0 = time.perf_counter()
+    g = Scene(sd, 0, abi.RT_BVH_LBVH_GPU)
+    t_gpu = time.perf_counter() - t0
+    g.check_bvh()
+    info = g.info()
+    assert info.n_triangles == sd.n_triangles and info.max_leaf_tris == 1 and info.n_nodes > sd.n_triangles // 8
+    t0 = time.perf_counter()
+    h = Scene(sd, 0, abi.RT_BVH_SAH)
+    t_host = time.perf_counter() - t0
+    print(f"scene create: GPU LBVH {t_gpu*1e3:.1f} ms, host SAH {t_host*1e3:.1f} ms")
+    g.close(), h.close()
+    for small in ("triangle", "cube", "empty"):  # fewer than 8 triangles: served by the host builder
+        s2 = Scene(scene_cache(small), 0, abi.RT_BVH_LBVH_GPU)
+        s2.check_bvh()
+        s2.close()
+
+
 @pytest.mark.parametrize("cls,kind", KINDS)
 def test_bvh_builder_does_not_change_the_image(gpu_scenes, cls, kind):
     frames = []
-    for bvh in (abi.RT_BVH_LBVH, abi.RT_BVH_SAH):
+    for bvh in (abi.RT_BVH_LBVH, abi.RT_BVH_SAH, abi.RT_BVH_LBVH_GPU):
         gs = gpu_scenes("atrium", bvh=bvh, detail=2)
         r = cls(gs, (320, 180), 10, 3)
         frames.append(r.render_frame(Camera.for_scene(gs.desc, (320, 180))))
         r.close()
-    assert frames[0].rays == frames[1].rays
-    np.testing.assert_array_equal(frames[0].rgba_f32, frames[1].rgba_f32)
+    for f in frames[1:]:
+        assert frames[0].rays == f.rays
+        np.testing.assert_array_equal(frames[0].rgba_f32, f.rgba_f32)
 
 
 @pytest.mark.parametrize("cls,kind", KINDS)

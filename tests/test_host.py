@@ -110,6 +110,7 @@ def test_scene_validation_errors(rtlib, scene_cache):
     assert rtlib.rt_scene_create(C.byref(c), -1, 0, C.byref(h)) == abi.RT_ERR_INVALID
     c = sd.to_c()
     assert rtlib.rt_scene_create(C.byref(c), -1, 99, C.byref(h)) == abi.RT_ERR_INVALID
+    assert rtlib.rt_scene_create(C.byref(c), -1, abi.RT_BVH_LBVH_GPU, C.byref(h)) == abi.RT_ERR_NO_DEVICE  # device build
 
 
 def test_camera_init_equals_oracle_bitwise(rtlib, oracle):
