@@ -8,9 +8,11 @@ from rtamd.renderer import Scene, Camera, MegakernelRenderer, WavefrontRenderer
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 W, H = 1920, 1080
 sd = scenes.atrium_scene(4); sc = Scene(sd, 0); cam = Camera.for_scene(sd, (W, H))
+only = sys.argv[2] if len(sys.argv) > 2 else ''
 for cls in (WavefrontRenderer, MegakernelRenderer):
+    if only and only.lower() not in cls.__name__.lower(): continue
     base = None
-    for world in (1, 2, 4, 8):
+    for world in (tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else (1, 2, 4, 8)):
         r = cls(sc, (W, H), 10, spp); r.set_tile(0, world, 8)
         r.render_frame(cam, want_f32=False, want_u8=False)
         best = min(r.render_frame(cam, want_f32=False, want_u8=False).device_ms for _ in range(3))

@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                                                     unsigned long long* __restrict__ ray_counter,
                                                     unsigned long long* __restrict__ stats_out) {
     WaveStats ws;
+    long long t_begin = 0, t_mark = 0, t_trav = 0, t_shade = 0;
+    if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
     const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)(threadIdx.x & 63u);
@@ -164,13 +166,18 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             continue;
         }
         // TRAVERSE until at least half of the live lanes are waiting for shading
+        if (STATS) t_mark = (long long)__builtin_readcyclecounter();
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live;
             (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
         }
-        if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
+        if (STATS) {
+            ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
+            const long long now = (long long)__builtin_readcyclecounter();
+            t_trav += now - t_mark, t_mark = now;
+        }
         // SHADE the lanes whose traversal is complete
         if (live && T.cur == kTravDone) {
             f3 res;
@@ -196,6 +203,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             }
             if (live) trav_begin(T, r.org, ray_dir(r));
         }
+        if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
     }
     const uint32_t total = wave_sum_u32(rays);
     if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
@@ -204,6 +212,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
         atomicAdd(stats_out + 4, (unsigned long long)ws.shade_rounds), atomicAdd(stats_out + 5, (unsigned long long)ws.shade_lanes);
         atomicAdd(stats_out + 6, (unsigned long long)ws.live_lane_steps), atomicAdd(stats_out + 7, (unsigned long long)ws.top_lanes);
+        // wave timeline (shader clock cycles): total residency, its maximum, time in traversal and in shading
+        const unsigned long long dur = (unsigned long long)((long long)__builtin_readcyclecounter() - t_begin);
+        atomicAdd(stats_out + 8, dur), atomicMax(stats_out + 9, dur), atomicAdd(stats_out + 10, 1ull);
+        atomicAdd(stats_out + 11, (unsigned long long)t_trav), atomicAdd(stats_out + 12, (unsigned long long)t_shade);
     }
 }
 

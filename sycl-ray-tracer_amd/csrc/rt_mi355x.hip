@@ -152,7 +152,7 @@ int alloc_tile_buffers(rt_renderer* r) {
     r->n_local = (uint32_t)r->tile.local_rows * (uint32_t)r->width;
     const size_t n = std::max<size_t>(r->n_local, 1);
     const char* ks = std::getenv("RT_KERNEL_STATS");
-    if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 8 * sizeof(unsigned long long)));
+    if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
     HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
@@ -228,7 +228,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
         } else if (r->d_stats) {
-            HIPCHK(hipMemsetAsync(r->d_stats, 0, 8 * sizeof(unsigned long long), st));
+            HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
@@ -241,7 +241,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         launches = 1;
     } else {
         const uint32_t D = r->max_depth;
-        if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 8 * sizeof(unsigned long long), st));
+        if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
         // fork: every lane's stream waits for what was enqueued on `st` so far, then runs its own chain
         HIPCHK(hipEventRecord(r->ev_fork, st));
         size_t ne_total = 0;
@@ -375,7 +375,7 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
         }
     }
     if (r->d_stats && r->n_local) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         const unsigned long long rays = local.rays;
         HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         std::fprintf(stderr,
@@ -384,6 +384,11 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
                      rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
                      h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
                      rays ? (double)h[1] / rays : 0.0, rays ? (double)h[7] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
+        if (h[10])
+            std::fprintf(stderr, "[rt stats] waves %llu | cycles per wave: mean %.0f, max %llu | traversal %.1f%%, shading %.1f%% of wave time | "
+                         "%.0f cycles per traversal step, %.0f per shade round\n",
+                         h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
+                         (h[0] + h[2]) ? (double)h[11] / (h[0] + h[2]) : 0.0, h[4] ? (double)h[12] / h[4] : 0.0);
     }
     if (stats) *stats = local;
     return RT_OK;
