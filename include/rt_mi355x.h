@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -178,6 +178,13 @@ int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row);
  * by the environment variable RT_PROFILE_KERNELS=1 at renderer creation. No reference counterpart
  * (the reference's print_elapsed helper is commented out: src/render_wavefront.cpp:129-137). */
 int rt_renderer_set_profiling(rt_renderer* r, int enable);
+
+/* Russian roulette, an EXTENSION: the reference only lists it as a to-do (PLAN.md:23-27) and never implements
+ * it, so it is off by default (start_bounce = 0) and changes the image and the ray count when turned on.
+ * A path that continues after its bounce b, start_bounce <= b < max_depth, survives with probability
+ * p = clamp(max component of its stored attenuation, 0.05, 1) (one extra RNG draw) and carries on with
+ * attenuation / p; otherwise it ends with no contribution. Same rule in both renderers and in the oracle. */
+int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
 
 typedef struct rt_stats {
     uint64_t rays;       /* trace_ray calls (src/render_megakernel.cpp:32, render_wavefront.cpp:407) */

@@ -45,7 +45,7 @@ def lib() -> C.CDLL:
         _lib.orc_scatter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                      _P(C.c_uint32), _P(C.c_uint8), _P(C.c_float), _P(C.c_float), _P(C.c_uint32)]
         _lib.orc_render.argtypes = [C.c_void_p, _P(abi.rt_camera), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
-                                    C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_uint8),
+                                    C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_uint8),
                                     _P(C.c_uint64)]
         _lib.orc_hardware_threads.restype = C.c_int
     return _lib
@@ -113,8 +113,9 @@ class OracleScene:
         return ok, od, oa, so
 
     def render(self, cam: abi.rt_camera, kind: int, max_depth: int, spp: int, seed_mode: int = 0, use_bvh: bool = True,
-               nthreads: int = 0, rank: int = 0, world: int = 1, strip_rows: int = 8):
-        """Returns (rgba_f32 [rows,W,4], rgba_u8 [rows,W,4], rays) for this rank's strips."""
+               nthreads: int = 0, rank: int = 0, world: int = 1, strip_rows: int = 8, rr_start: int = 0):
+        """Returns (rgba_f32 [rows,W,4], rgba_u8 [rows,W,4], rays) for this rank's strips. rr_start > 0 turns on the
+        Russian-roulette extension from that bounce on (off in every parity run against the reference's semantics)."""
         W, H = cam.width, cam.height
         rows = sum(1 for y in range(H) if (y // strip_rows) % world == rank)
         f = np.zeros((rows, W, 4), np.float32)
@@ -123,7 +124,7 @@ class OracleScene:
         if nthreads <= 0:
             nthreads = hardware_threads()
         rc = lib().orc_render(self.h, C.byref(cam), kind, seed_mode, max_depth, spp, int(use_bvh), nthreads, rank, world,
-                              strip_rows, abi.fptr(f), abi.u8ptr(b), C.byref(rays))
+                              strip_rows, rr_start, abi.fptr(f), abi.u8ptr(b), C.byref(rays))
         assert rc == 0
         return f, b, rays.value
 

@@ -574,9 +574,26 @@ inline uint32_t seed_for(int x, int y, int w, int h, uint32_t seed_mode) {
     return (uint32_t)x + (uint32_t)y * (uint32_t)w; // src/render_wavefront.cpp:69-73
 }
 
+// Russian roulette — an EXTENSION (the reference only lists it as a to-do: PLAN.md:23-27), off unless
+// rr_start > 0, never part of a parity run against the reference's own numbers. Applied to a path that
+// continues after its bounce number b (1-based) when rr_start <= b < max_depth:
+//   q = the attenuation as it is stored (three halves);  p = min(max(max(q.r,q.g,q.b), 0.05), 1);
+//   one draw u;  the path survives iff u < p and carries on with q / p (three fp32 divisions),
+//   otherwise it ends and contributes (0,0,0) like a path that outlives max_depth.
+inline bool roulette(Rng& rng, V3& att) {
+    uint16_t h[3];
+    store3(h, att);
+    const V3 q = load3(h);
+    const float p = fminf(fmaxf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.05f), 1.0f);
+    const float u = rng.next();
+    if (!(u < p)) return false;
+    att = mk(q.x / p, q.y / p, q.z / p);
+    return true;
+}
+
 // render_pixel: src/render_megakernel.cpp:20-63
 inline V3 render_pixel(const Scene& sc, bool use_bvh, const rt_camera& cam, Rng& rng, int x, int y,
-                       uint32_t max_depth, uint64_t& ray_count) {
+                       uint32_t max_depth, uint32_t rr_start, uint64_t& ray_count) {
     Ray rd = get_ray(cam, x, y, rng);
     for (uint32_t i = 0; i < max_depth; ++i) {
         ray_count++;
@@ -586,6 +603,7 @@ inline V3 render_pixel(const Scene& sc, bool use_bvh, const rt_camera& cam, Rng&
         V3 dir = load3(rd.dir);
         V3 res;
         bool done = trace_ray(sc, use_bvh, rng, org, dir, att, rad, res);
+        if (!done && rr_start && i + 1 >= rr_start && i + 1 < max_depth && !roulette(rng, att)) return mk(0.0f, 0.0f, 0.0f);
         rd.org = org;
         store3(rd.dir, dir);
         store3(rd.att, att);
@@ -711,7 +729,7 @@ int orc_scatter(const orc_scene* s, uint32_t material, uint32_t n, const float* 
 //       340-354,377-390,396-417) with per-sample queues.
 int orc_render(const orc_scene* s, const rt_camera* cam, int kind, uint32_t seed_mode,
                uint32_t max_depth, uint32_t spp, int use_bvh, int nthreads, uint32_t rank,
-               uint32_t world, uint32_t strip_rows, float* rgba_f32, uint8_t* rgba_u8,
+               uint32_t world, uint32_t strip_rows, uint32_t rr_start, float* rgba_f32, uint8_t* rgba_u8,
                uint64_t* rays_out) {
     if (!s || !cam || world == 0 || rank >= world || strip_rows == 0) return -1;
     const Scene& sc = s->sc;
@@ -749,7 +767,7 @@ int orc_render(const orc_scene* s, const rt_camera* cam, int kind, uint32_t seed
                 Rng rng{seed_for(x, y, W, H, seed_mode)};
                 V3 color = mk(0, 0, 0);
                 for (uint32_t i = 0; i < spp; ++i)
-                    color = color + render_pixel(sc, bvh, *cam, rng, x, y, max_depth, rays);
+                    color = color + render_pixel(sc, bvh, *cam, rng, x, y, max_depth, rr_start, rays);
                 color = color / (float)spp;                             // :154
                 emit(lr, x, mk(sqrtf(color.x), sqrtf(color.y), sqrtf(color.z))); // linear_to_gamma :156
             }
@@ -811,11 +829,13 @@ int orc_render(const orc_scene* s, const rt_camera* cam, int kind, uint32_t seed
                         Rng rng{rngs[id]};
                         V3 res;
                         bool done = trace_ray(sc, bvh, rng, org, dir, att, rad, res);
+                        bool killed = false;
+                        if (!done && rr_start && depth + 1 >= rr_start && depth + 1 < max_depth) killed = !roulette(rng, att);
                         rngs[id] = rng.a;
                         if (done) { // :275-278
                             image[4 * id] = clamp01(res.x), image[4 * id + 1] = clamp01(res.y);
                             image[4 * id + 2] = clamp01(res.z), image[4 * id + 3] = 1.0f;
-                        } else if (depth == max_depth - 1) { // :279-280
+                        } else if (depth == max_depth - 1 || killed) { // :279-280
                             image[4 * id] = image[4 * id + 1] = image[4 * id + 2] = 0.0f;
                             image[4 * id + 3] = 1.0f;
                         } else { // :281-292

@@ -70,6 +70,16 @@ RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hi
     return done;
 }
 
+// Russian roulette on a continuing path (extension, see rt_renderer_set_russian_roulette); false = path ends
+RT_DEV bool roulette(uint32_t& rng, RayState& r) {
+    const float qx = h2f(r.att[0]), qy = h2f(r.att[1]), qz = h2f(r.att[2]);
+    const float p = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(qx, __builtin_fmaxf(qy, qz)), 0.05f), 1.0f);
+    const float u = rng_next(rng);
+    if (!(u < p)) return false;
+    r.att[0] = f2h(qx / p), r.att[1] = f2h(qy / p), r.att[2] = f2h(qz / p);
+    return true;
+}
+
 RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -100,7 +110,7 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
-                                                    uint32_t spp, uint32_t seed_mode, float* __restrict__ out_f32,
+                                                    uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
                                                     unsigned long long* __restrict__ stats_out) {
@@ -184,7 +194,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             rays++;
             const bool done = shade_bounce(S, rng, r, T.best, res);
             depth++;
-            if (done || depth == max_depth) {
+            bool killed = false;
+            if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
+            if (done || killed || depth == max_depth) {
                 if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
                 s++;
                 depth = 0;
@@ -369,7 +381,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
 __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, QueueDev qout, const float4* __restrict__ hits,
                                                    uint32_t* __restrict__ rng, float4* __restrict__ accum,
                                                    const uint32_t* __restrict__ count_in,
-                                                   uint32_t* __restrict__ count_out, int last_depth) {
+                                                   uint32_t* __restrict__ count_out, int last_depth, int rr_active) {
     __shared__ uint32_t wave_total[4];
     __shared__ uint32_t block_base;
     const uint32_t n = *count_in;
@@ -386,14 +398,15 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
         uint32_t st = rng[id]; // ScopedRng load (src/render_wavefront.cpp:15-32)
         f3 res;
         const bool done = shade_bounce(S, st, r, hit, res);
-        rng[id] = st;          // ScopedRng store
         if (done) {
             float4 acc = accum[id];
             acc.x = acc.x + clamp01(res.x), acc.y = acc.y + clamp01(res.y), acc.z = acc.z + clamp01(res.z);
             accum[id] = acc;
         } else {
             survive = !last_depth; // survivors of the last depth contribute (0,0,0) (:279-280)
+            if (rr_active && survive) survive = roulette(st, r);
         }
+        rng[id] = st;          // ScopedRng store
     }
     const unsigned long long mask = __ballot(survive);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

@@ -95,6 +95,7 @@ struct rt_renderer {
     uint8_t* d_u8 = nullptr;
     // megakernel
     unsigned long long* d_ray_counter = nullptr;
+    uint32_t rr_start = 0;                 // Russian roulette from this bounce on (0 = off, the reference's behaviour)
     unsigned long long* d_stats = nullptr; // RT_KERNEL_STATS=1: wave scheduling statistics (diagnostic)
     // wavefront: the tile is rendered as K interleaved sub-tiles ("lanes"), each with its own queues and
     // its own HIP stream. The lanes' launch chains are independent, so the drain tail of one lane's EXTEND
@@ -230,10 +231,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
             hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
+                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
@@ -297,7 +298,8 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                         ne[k] += 2;
                     }
                     hipLaunchKernelGGL(k_wf_shade, dim3(grid[k]), dim3(256), 0, ls, S, L.q[buf[k]], L.q[buf[k] ^ 1], L.d_hits, L.d_rng,
-                                       L.d_accum, counts + d, counts + d + 1, d + 1 == D ? 1 : 0);
+                                       L.d_accum, counts + d, counts + d + 1, d + 1 == D ? 1 : 0,
+                                       r->rr_start && d + 1 >= r->rr_start && d + 1 < D ? 1 : 0);
                     launches += 2;
                     buf[k] ^= 1;
                 }
@@ -609,6 +611,12 @@ int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row) {
 int rt_renderer_set_profiling(rt_renderer* r, int enable) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
     r->profile_kernels = enable != 0;
+    return RT_OK;
+}
+
+int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    r->rr_start = start_bounce;
     return RT_OK;
 }
 

@@ -3,7 +3,7 @@
 //   -d,--max-depth N       (10)       -s,--sample-count N  (32)      scene_path (./assets/sponza.glb)
 //   -w,--wavefront         -m,--megakernel        neither => wavefront
 // Extensions (the reference hard-codes 1920x1080, one device, out.png):
-//   --width N --height N   --device N   --out FILE   --bvh {sah,lbvh}   --quiet
+//   --width N --height N   --device N   --out FILE   --bvh {sah,lbvh}   --rr N   --quiet
 // Prints the same lines as the reference (Loading scene, loader chatter, Sample n, the three statistics
 // lines benchmark.py scrapes, Writing image to disk) and writes the PNG.
 #include <cstdio>
@@ -27,12 +27,13 @@ static void usage(const char* argv0) {
                 "  --device INT                HIP device (default 0)\n"
                 "  --out FILE                  Output PNG (default out.png)\n"
                 "  --bvh sah|lbvh              BVH builder (default sah)\n"
+                "  --rr UINT                   Russian roulette from this bounce on (default 0 = off, as the reference)\n"
                 "  --quiet                     No loader chatter\n",
                 argv0);
 }
 
 int main(int argc, const char* argv[]) {
-    uint32_t max_depth = 10, sample_count = 32;
+    uint32_t max_depth = 10, sample_count = 32, rr = 0;
     std::string scene_path = "./assets/sponza.glb", out_path = "out.png";
     bool use_wavefront = false, use_megakernel = false, quiet = false;
     int32_t width = 1920, height = 1080;
@@ -68,6 +69,7 @@ int main(int argc, const char* argv[]) {
         else if (a == "--height") height = (int32_t)to_u32("--height", need(i));
         else if (a == "--device") device = (int)to_u32("--device", need(i));
         else if (a == "--out") out_path = need(i);
+        else if (a == "--rr") rr = to_u32("--rr", need(i));
         else if (a == "--quiet") quiet = true;
         else if (a == "--bvh") {
             const std::string v = need(i);
@@ -99,10 +101,12 @@ int main(int argc, const char* argv[]) {
         if (use_megakernel) {
             auto* r = new raytracer::MegakernelRenderer({width, height}, image_buf.data(), max_depth, sample_count);
             r->out_path = out_path;
+            r->russian_roulette = rr;
             renderer.reset(r);
         } else {
             auto* r = new raytracer::WavefrontRenderer({width, height}, image_buf.data(), max_depth, sample_count);
             r->out_path = out_path;
+            r->russian_roulette = rr;
             renderer.reset(r);
         }
         renderer->render_frame(camera, scene);

@@ -67,6 +67,7 @@ struct HipRendererBase : public IRenderer {
     const Scene* bound = nullptr;
     int kind;
     std::string out_path = "out.png"; // src/util.hpp:27
+    uint32_t russian_roulette = 0;    // extension, 0 = off (rt_renderer_set_russian_roulette)
     rt_stats last{};
 
     HipRendererBase(int kind, std::array<int32_t, 2> img_size, uint8_t* image, uint32_t max_depth, uint32_t sample_count)
@@ -80,6 +81,7 @@ struct HipRendererBase : public IRenderer {
             rt_check(rt_renderer_create(kind, scene.handle, img_size[0], img_size[1], max_depth, sample_count, RT_SEED_DEFAULT, &handle));
             bound = &scene;
         }
+        rt_check(rt_renderer_set_russian_roulette(handle, russian_roulette));
         if (kind == RT_RENDERER_WAVEFRONT)
             for (uint32_t s = 0; s < sample_count; ++s) std::printf("Sample %u\n", s); // src/render_wavefront.cpp:402
         rt_check(rt_render_frame(handle, &camera.c, nullptr, image, &last));

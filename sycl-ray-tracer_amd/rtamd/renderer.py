@@ -127,6 +127,10 @@ class IRenderer:
     def set_profiling(self, enable: bool) -> None:
         abi.check(self._lib.rt_renderer_set_profiling(self.h, int(enable)))
 
+    def set_russian_roulette(self, start_bounce: int) -> None:
+        """Extension (a to-do upstream: PLAN.md:23-27): paths are thinned from bounce `start_bounce` on; 0 = off (default)."""
+        abi.check(self._lib.rt_renderer_set_russian_roulette(self.h, int(start_bounce)))
+
     @property
     def local_rows(self) -> int:
         return int(self._lib.rt_renderer_local_rows(self.h))
