@@ -105,6 +105,9 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_SHADE_PCT
 #define RT_MEGA_SHADE_PCT 50u // shade when this share of the live lanes is waiting
 #endif
+#ifndef RT_MEGA_TAIL_SHADE_PCT
+#define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
+#endif
 #ifndef RT_MEGA_BLOCK
 #define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
 #endif
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         if (STATS) t_mark = (long long)__builtin_readcyclecounter();
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
             if (STATS) ws.live_lane_steps += n_live;
             (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
         }
@@ -240,10 +243,11 @@ __global__ void __launch_bounds__(256) k_fill_black(uint32_t n_local, float* __r
 }
 
 // ---- K2: seed RNG states, zero the accumulator --------------------------------------------------------
-__global__ void __launch_bounds__(256) k_wf_init(CameraDev cam, TileDev tile, uint32_t seed_mode, uint32_t n_local,
+__global__ void __launch_bounds__(256) k_wf_init(const CameraDev* __restrict__ camp, TileDev tile, uint32_t seed_mode, uint32_t n_local,
                                                   uint32_t* __restrict__ rng, float4* __restrict__ accum) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_local) return;
+    const CameraDev cam = *camp; // in device memory, not a kernel argument: the frame's launches replay as a hipGraph
     const int x = (int)(i % (uint32_t)cam.width), ly = (int)(i / (uint32_t)cam.width);
     const int gy = tile_global_row(tile, ly);
     rng[i] = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
@@ -251,12 +255,13 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraDev cam, TileDev tile, ui
 }
 
 // ---- K3: camera rays for every pixel of the tile into queue slot = local pixel index -----------------
-__global__ void __launch_bounds__(256) k_wf_generate(CameraDev cam, TileDev tile, uint32_t n_local,
+__global__ void __launch_bounds__(256) k_wf_generate(const CameraDev* __restrict__ camp, TileDev tile, uint32_t n_local,
                                                       uint32_t* __restrict__ rng, QueueDev q,
                                                       uint32_t* __restrict__ count_out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) *count_out = n_local; // "*ray_buffer_length = img_size.size()" (src/render_wavefront.cpp:104)
     if (i >= n_local) return;
+    const CameraDev cam = *camp;
     const int x = (int)(i % (uint32_t)cam.width), ly = (int)(i / (uint32_t)cam.width);
     const int gy = tile_global_row(tile, ly);
     uint32_t st = rng[i];

@@ -502,3 +502,23 @@ def test_russian_roulette_extension_equals_the_oracle(oracle, scene_cache, rr):
         np.testing.assert_array_equal(again.rgba_f32, base.rgba_f32)
         r.close()
     gs.close()
+
+
+def test_wavefront_frame_replayed_as_a_hip_graph_is_identical(oracle, scene_cache, monkeypatch):
+    """RT_WF_GRAPH=1 captures the frame's launch sequence (both streams) into a hipGraph and replays it per frame: same
+    image and ray count, also after the camera moves (the camera is the graph's only per-frame input)."""
+    sd = scene_cache("cornell")
+    gs, osc = Scene(sd, 0), oracle.OracleScene(sd)
+    w, h = 80, 64
+    monkeypatch.setenv("RT_WF_GRAPH", "1")
+    r = WavefrontRenderer(gs, (w, h), 6, 5)
+    monkeypatch.delenv("RT_WF_GRAPH")
+    for pos in (sd.camera.position, tuple(np.asarray(sd.camera.position) + np.array([0.2, -0.1, 0.3])), sd.camera.position):
+        cam = Camera((w, h), pos, sd.camera.direction, sd.camera.focal_length)
+        fr = r.render_frame(cam)
+        f, b, rays = osc.render(oracle.camera(w, h, pos, sd.camera.direction, sd.camera.focal_length), abi.RT_RENDERER_WAVEFRONT, 6, 5)
+        assert fr.rays == rays
+        np.testing.assert_array_equal(fr.rgba_f32, f)
+        np.testing.assert_array_equal(fr.rgba_u8, b)
+    r.close()
+    gs.close()
