@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
 MEGAKERNEL_BYTES_PER_PIXEL = 20  # one fp32 RGBA store + one RGBA8 store per pixel per frame
+# SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 48-B triangle records, 124 B of hit shading;
+# the per-ray counts are the atrium's, measured with RT_KERNEL_STATS=1: 17.88 nodes, 4.52 triangles
+TRAVERSAL_BYTES_PER_RAY = 17.88 * 64 + 4.52 * 48 + 124
 
 
 def main() -> int:
@@ -71,7 +74,15 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, gather, all-reduces) even with one
+    # rank — a one-GPU rehearsal of what the N > 1 runs execute
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, strip = args.width, args.height, 8
@@ -79,11 +90,11 @@ def main() -> int:
     scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
     cam = Camera.for_scene(sd, (W, H))
     from rtamd.dist import FrameGatherer
-    fg = FrameGatherer(rank, world, W, H, strip, dev)
+    fg = FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist)
     local = fg.local
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +128,7 @@ def main() -> int:
         rows = r.local_rows
         r.close()
         rays_all = float(rays)
-        if world > 1:
+        if use_dist:
             mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             sm = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
@@ -140,6 +151,8 @@ def main() -> int:
             roof["concurrent_streams"] = 2  # two sub-tiles on two streams: a launch shares the chip with its twin
             roof["note"] = "incoherent BVH traversal is bound by gather latency and VALU issue; the HBM fraction is small by construction (DESIGN.md §6)"
         else:
+            roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache
+            roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
             roof["note"] = ("the megakernel has no per-ray HBM stream (SURVEY.md §8d): its only algorithmic HBM traffic is the frame store; "
                             "its BVH gathers are served by L2 / Infinity Cache (profiles/r01_traffic.json)")
         traffic_file = REPO / "profiles" / "r01_traffic.json"
@@ -174,7 +187,7 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return 0
 

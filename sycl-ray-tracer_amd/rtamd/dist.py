@@ -25,14 +25,15 @@ class FrameGatherer:
     collective and the de-interleave copies."""
 
     def __init__(self, rank: int, world: int, width: int, height: int, strip_rows: int, device: torch.device,
-                 channels: int = 4, dtype=torch.float32):
+                 channels: int = 4, dtype=torch.float32, collective: bool | None = None):
         self.rank, self.world, self.height = rank, world, height
+        self.collective = world > 1 if collective is None else bool(collective)  # True with one rank: rehearsal
         self.rows = len(strip_rows_of(rank, world, height, strip_rows))
         pad_rows = max_local_rows(world, height, strip_rows)
         # every rank contributes the same (padded) shape: torch.distributed.gather needs equal sizes
         self.local = torch.zeros((pad_rows, width, channels), dtype=dtype, device=device)
         self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
-        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and world > 1) else None
+        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and self.collective) else None
         self.index = None
         if rank == 0:
             self.index = [torch.tensor(strip_rows_of(r, world, height, strip_rows), dtype=torch.long, device=device)
@@ -40,11 +41,15 @@ class FrameGatherer:
 
     def gather(self):
         """Collects `self.local` of every rank into `self.frame` on rank 0. Returns the frame (rank 0) or None."""
-        if self.world > 1:
+        if self.collective:
             dist.gather(self.local, self.parts, dst=0)
             if self.rank == 0:
                 for r in range(self.world):
                     self.frame.index_copy_(0, self.index[r], self.parts[r][: self.index[r].numel()])
         else:
             self.frame.index_copy_(0, self.index[0], self.local[: self.rows])
+        # The renderer writes `self.local` from its own HIP stream: the next frame must not start before this
+        # exchange has read it (and rank 0's frame is complete when gather() returns).
+        if self.local.is_cuda:
+            torch.cuda.current_stream(self.local.device).synchronize()
         return self.frame
