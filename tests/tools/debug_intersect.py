@@ -1,6 +1,7 @@
+"""Developer tool (uses the oracle as the checker, hence under tests/): prints where GPU and oracle differ."""
 import sys
 from pathlib import Path
-REPO = Path(__file__).resolve().parent.parent
+REPO = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
 import numpy as np
 from oracle import oracle as O
