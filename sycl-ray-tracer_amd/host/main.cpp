@@ -3,7 +3,7 @@
 //   -d,--max-depth N       (10)       -s,--sample-count N  (32)      scene_path (./assets/sponza.glb)
 //   -w,--wavefront         -m,--megakernel        neither => wavefront
 // Extensions (the reference hard-codes 1920x1080, one device, out.png):
-//   --width N --height N   --device N   --out FILE   --bvh {sah,lbvh}   --rr N   --quiet
+//   --width N --height N   --device N   --devices A,B,..   --out FILE   --bvh {sah,lbvh}   --rr N   --quiet
 // Prints the same lines as the reference (Loading scene, loader chatter, Sample n, the three statistics
 // lines benchmark.py scrapes, Writing image to disk) and writes the PNG.
 #include <cstdio>
@@ -25,6 +25,7 @@ static void usage(const char* argv0) {
                 "  -m,--megakernel             Use megakernel renderer\n"
                 "  --width UINT --height UINT  Image size (default 1920x1080)\n"
                 "  --device INT                HIP device (default 0)\n"
+                "  --devices A,B,...           tile the frame over these HIP devices (8-row strips, one host thread each)\n"
                 "  --out FILE                  Output PNG (default out.png)\n"
                 "  --bvh sah|lbvh              BVH builder (default sah)\n"
                 "  --rr UINT                   Russian roulette from this bounce on (default 0 = off, as the reference)\n"
@@ -38,6 +39,7 @@ int main(int argc, const char* argv[]) {
     bool use_wavefront = false, use_megakernel = false, quiet = false;
     int32_t width = 1920, height = 1080;
     int device = 0, bvh = RT_BVH_DEFAULT;
+    std::vector<int> devices;
     bool have_scene = false;
 
     auto need = [&](int& i) -> const char* {
@@ -68,6 +70,17 @@ int main(int argc, const char* argv[]) {
         else if (a == "--width") width = (int32_t)to_u32("--width", need(i));
         else if (a == "--height") height = (int32_t)to_u32("--height", need(i));
         else if (a == "--device") device = (int)to_u32("--device", need(i));
+        else if (a == "--devices") {
+            const std::string v = need(i);
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                const size_t comma = v.find(',', pos);
+                const std::string tok = v.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                devices.push_back((int)to_u32("--devices", tok.c_str()));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+        }
         else if (a == "--out") out_path = need(i);
         else if (a == "--rr") rr = to_u32("--rr", need(i));
         else if (a == "--quiet") quiet = true;
@@ -93,7 +106,15 @@ int main(int argc, const char* argv[]) {
     try {
         const int n_dev = rt_device_count();
         if (n_dev <= 0) throw std::runtime_error(std::string("no HIP device: ") + rt_last_error());
-        std::printf("Running on device: HIP device %d of %d (gfx950 path)\n", device, n_dev); // src/app.hpp:51-54
+        for (int d : devices)
+            if (d >= n_dev) throw std::runtime_error("--devices: HIP device " + std::to_string(d) + " does not exist");
+        if (!devices.empty()) device = devices[0];
+        if (devices.size() > 1) {
+            std::printf("Running on devices:");
+            for (int d : devices) std::printf(" %d", d);
+            std::printf(" of %d (gfx950 path, frame tiled in 8-row strips)\n", n_dev);
+        } else
+            std::printf("Running on device: HIP device %d of %d (gfx950 path)\n", device, n_dev); // src/app.hpp:51-54
         std::vector<uint8_t> image_buf((size_t)width * (size_t)height * 4);
         raytracer::Scene scene(scene_path, device, bvh, !quiet);
         raytracer::Camera camera({width, height}, scene.camera_position, scene.camera_direction, scene.camera_focal_length);
@@ -102,11 +123,13 @@ int main(int argc, const char* argv[]) {
             auto* r = new raytracer::MegakernelRenderer({width, height}, image_buf.data(), max_depth, sample_count);
             r->out_path = out_path;
             r->russian_roulette = rr;
+            r->devices = devices;
             renderer.reset(r);
         } else {
             auto* r = new raytracer::WavefrontRenderer({width, height}, image_buf.data(), max_depth, sample_count);
             r->out_path = out_path;
             r->russian_roulette = rr;
+            r->devices = devices;
             renderer.reset(r);
         }
         renderer->render_frame(camera, scene);

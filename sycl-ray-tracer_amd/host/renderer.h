@@ -10,11 +10,15 @@
 //   raytracer::WavefrontRenderer    == src/render_wavefront.hpp:40-76,  render_frame src/render_wavefront.cpp:396-431
 #pragma once
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -38,11 +42,13 @@ struct Camera {
 struct Scene {
     rthost::LoadedScene data;
     rt_scene* handle = nullptr;
+    int device = 0, bvh_kind = RT_BVH_DEFAULT;
+    mutable std::map<int, rt_scene*> replicas; // device -> scene replica (multi-GPU frames), built on first use
     float camera_position[3], camera_direction[3], camera_focal_length;
 
     // Scene(app, filepath): src/scene.cpp:54-129. `device` replaces App's SYCL device.
     Scene(const std::string& filepath, int device = 0, int bvh_kind = RT_BVH_DEFAULT, bool verbose = true)
-        : data(rthost::load_glb(filepath, verbose)) {
+        : data(rthost::load_glb(filepath, verbose)), device(device), bvh_kind(bvh_kind) {
         for (int k = 0; k < 3; ++k) camera_position[k] = data.camera_position[k], camera_direction[k] = data.camera_direction[k];
         camera_focal_length = data.camera_focal_length;
         const rt_scene_desc d = data.desc();
@@ -50,7 +56,21 @@ struct Scene {
     }
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
-    ~Scene() { rt_scene_destroy(handle); }
+    ~Scene() {
+        for (auto& kv : replicas) rt_scene_destroy(kv.second);
+        rt_scene_destroy(handle);
+    }
+    // the scene on `dev`: the primary handle or a replica (every GPU of a tiled frame holds the whole scene + BVH)
+    rt_scene* on_device(int dev) const {
+        if (dev == device) return handle;
+        auto it = replicas.find(dev);
+        if (it != replicas.end()) return it->second;
+        const rt_scene_desc d = data.desc();
+        rt_scene* h = nullptr;
+        rt_check(rt_scene_create(&d, dev, bvh_kind, &h));
+        replicas[dev] = h;
+        return h;
+    }
 };
 
 struct IRenderer {
@@ -68,13 +88,73 @@ struct HipRendererBase : public IRenderer {
     int kind;
     std::string out_path = "out.png"; // src/util.hpp:27
     uint32_t russian_roulette = 0;    // extension, 0 = off (rt_renderer_set_russian_roulette)
+    // Extension: more than one entry tiles the frame over these HIP devices in THIS process, one host thread per
+    // tile (interleaved 8-row strips, tile k -> devices[k]; the same device may appear more than once). The
+    // one-process-per-GPU RCCL path is rtamd/dist.py + bench.py; this one serves the CLI, whose image ends up in
+    // host memory for the PNG anyway.
+    std::vector<int> devices;
+    std::vector<rt_renderer*> tile_handles;
     rt_stats last{};
 
     HipRendererBase(int kind, std::array<int32_t, 2> img_size, uint8_t* image, uint32_t max_depth, uint32_t sample_count)
         : img_size(img_size), image(image), max_depth(max_depth), sample_count(sample_count), kind(kind) {}
-    ~HipRendererBase() override { rt_renderer_destroy(handle); }
+    ~HipRendererBase() override {
+        for (rt_renderer* h : tile_handles) rt_renderer_destroy(h);
+        rt_renderer_destroy(handle);
+    }
+
+    // one frame over devices.size() tiles: returns with `image` assembled and `last` = summed rays / wall time
+    void render_tiled(const Camera& camera, const Scene& scene) {
+        const uint32_t G = (uint32_t)devices.size();
+        if (tile_handles.empty() || bound != &scene) {
+            for (rt_renderer* h : tile_handles) rt_renderer_destroy(h);
+            tile_handles.assign(G, nullptr);
+            for (uint32_t k = 0; k < G; ++k) {
+                rt_check(rt_renderer_create(kind, scene.on_device(devices[k]), img_size[0], img_size[1], max_depth, sample_count,
+                                            RT_SEED_DEFAULT, &tile_handles[k]));
+                rt_check(rt_renderer_set_tile(tile_handles[k], k, G, 8));
+            }
+            bound = &scene;
+        }
+        const size_t row_bytes = (size_t)img_size[0] * 4;
+        std::vector<std::vector<uint8_t>> part(G);
+        std::vector<rt_stats> st(G);
+        std::vector<std::string> err(G);
+        std::vector<std::thread> threads;
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        for (uint32_t k = 0; k < G; ++k) {
+            threads.emplace_back([&, k]() {
+                rt_renderer* h = tile_handles[k];
+                part[k].resize((size_t)rt_renderer_local_rows(h) * row_bytes + 4);
+                if (rt_renderer_set_russian_roulette(h, russian_roulette) != RT_OK ||
+                    rt_render_frame(h, &camera.c, nullptr, part[k].data(), &st[k]) != RT_OK)
+                    err[k] = rt_last_error(); // rt_last_error is per thread
+            });
+        }
+        for (auto& t : threads) t.join();
+        const double wall = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        for (uint32_t k = 0; k < G; ++k)
+            if (!err[k].empty()) throw std::runtime_error("librt_mi355x (tile " + std::to_string(k) + "): " + err[k]);
+        last = rt_stats{};
+        for (uint32_t k = 0; k < G; ++k) {
+            const int32_t rows = rt_renderer_local_rows(tile_handles[k]);
+            for (int32_t lr = 0; lr < rows; ++lr)
+                std::memcpy(image + (size_t)rt_renderer_global_row(tile_handles[k], lr) * row_bytes, part[k].data() + (size_t)lr * row_bytes, row_bytes);
+            last.rays += st[k].rays;
+            last.launches += st[k].launches;
+            last.device_ms = std::max(last.device_ms, st[k].device_ms);
+        }
+        last.seconds = wall;
+    }
 
     void render_frame(const Camera& camera, const Scene& scene) override {
+        if (devices.size() > 1) {
+            if (kind == RT_RENDERER_WAVEFRONT)
+                for (uint32_t s = 0; s < sample_count; ++s) std::printf("Sample %u\n", s);
+            render_tiled(camera, scene);
+            report_and_write(last.seconds); // tiles run concurrently: the frame time is the wall time of the slowest
+            return;
+        }
         if (!handle || bound != &scene) { // the ray queues belong to a scene's device: created on first use
             rt_renderer_destroy(handle);
             handle = nullptr;
@@ -85,7 +165,10 @@ struct HipRendererBase : public IRenderer {
         if (kind == RT_RENDERER_WAVEFRONT)
             for (uint32_t s = 0; s < sample_count; ++s) std::printf("Sample %u\n", s); // src/render_wavefront.cpp:402
         rt_check(rt_render_frame(handle, &camera.c, nullptr, image, &last));
-        const double secs = last.device_ms * 1e-3;
+        report_and_write(last.device_ms * 1e-3);
+    }
+
+    void report_and_write(double secs) {
         const double rays_per_sec = secs > 0 ? (double)last.rays / secs : 0.0;
         // the three lines benchmark.py scrapes (src/render_wavefront.cpp:425-427, benchmark.py:49-55)
         std::printf("Time measured: %.6f seconds\n", secs);

@@ -70,3 +70,19 @@ def test_cli_on_an_exported_scene_with_camera_textures_and_extensions(rtlib, tmp
 def test_cli_failures_are_reported_not_fatal(rtlib, tmp_path):
     p = subprocess.run([str(EXE), "-s", "1", str(tmp_path / "missing.glb")], capture_output=True, text=True)
     assert p.returncode == 1 and "Failed to load .glTF" in p.stdout
+
+
+@pytest.mark.parametrize("flag", ["-m", "-w"])
+def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, tmp_path, flag):
+    """--devices A,B,C: interleaved 8-row strips, one host thread and one renderer per tile (here three tiles on the
+    one GPU of the box, which exercises everything except a second physical device): the PNG and the ray count are
+    those of the single-device run, and a device that does not exist is refused."""
+    from PIL import Image
+    common = ["-d", 6, "-s", 3, "--width", 200, "--height", 150, "--quiet", flag, REPO / "assets" / "cube.glb"]
+    _, rays1 = _run(["--out", tmp_path / "one.png"] + common, tmp_path)
+    out3, rays3 = _run(["--devices", "0,0,0", "--out", tmp_path / "three.png"] + common, tmp_path)
+    assert "Running on devices: 0 0 0" in out3
+    assert rays3 == rays1
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "three.png")), np.asarray(Image.open(tmp_path / "one.png")))
+    p = subprocess.run([str(EXE), "--devices", "0,99", "-s", "1", str(REPO / "assets" / "cube.glb")], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 1 and "does not exist" in p.stdout

@@ -163,7 +163,7 @@ def test_cli_flags_match_the_reference(rtlib):
     assert exe.exists()
     out = subprocess.run([str(exe), "--help"], capture_output=True, text=True)
     assert out.returncode == 0
-    for flag in ("-d,--max-depth", "-s,--sample-count", "-w,--wavefront", "-m,--megakernel", "scene_path", "--rr"):
+    for flag in ("-d,--max-depth", "-s,--sample-count", "-w,--wavefront", "-m,--megakernel", "scene_path", "--rr", "--devices"):
         assert flag in out.stdout
     bad = subprocess.run([str(exe), "--nope"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not expected" in bad.stderr
