@@ -3,6 +3,7 @@
 #include <cstring>
 #include <string>
 
+#include "jpeg.h"
 #include "png.h"
 #include "scene_loader.h"
 
@@ -45,6 +46,19 @@ int rth_decode_png(const uint8_t* data, size_t size, uint32_t* w, uint32_t* h, u
     try {
         std::vector<uint8_t> rgba;
         decode_png_rgba8(data, size, *w, *h, rgba);
+        if (rgba.size() > capacity) { g_err = "output buffer too small"; return -1; }
+        std::memcpy(out, rgba.data(), rgba.size());
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+// PNG or JPEG by signature, as the loader decodes embedded textures
+int rth_decode_image(const uint8_t* data, size_t size, uint32_t* w, uint32_t* h, uint8_t* out, size_t capacity) {
+    try {
+        std::vector<uint8_t> rgba;
+        decode_image_rgba8(data, size, *w, *h, rgba);
         if (rgba.size() > capacity) { g_err = "output buffer too small"; return -1; }
         std::memcpy(out, rgba.data(), rgba.size());
         return 0;

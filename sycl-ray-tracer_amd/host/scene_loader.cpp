@@ -11,6 +11,7 @@
 #include <stdexcept>
 
 #include "json.h"
+#include "jpeg.h"
 #include "png.h"
 
 namespace rthost {
@@ -159,50 +160,7 @@ void read_floats(const View& v, int ncomp, std::vector<float>& out) {
     }
 }
 
-float srgb_to_linear(uint8_t c) {
-    float x = (float)c / 255.0f;
-    return x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
-}
-uint8_t linear_to_srgb(float x) {
-    x = std::min(1.0f, std::max(0.0f, x));
-    float y = x <= 0.0031308f ? x * 12.92f : 1.055f * std::pow(x, 1.0f / 2.4f) - 0.055f;
-    return (uint8_t)std::lrintf(std::min(1.0f, std::max(0.0f, y)) * 255.0f);
-}
-
 } // namespace
-
-void resize_to_layer(const uint8_t* rgba, uint32_t w, uint32_t h, uint8_t* out) {
-    constexpr uint32_t N = RT_TEX_SIZE;
-    if (w == N && h == N) {
-        std::memcpy(out, rgba, (size_t)N * N * 4);
-        return;
-    }
-    // linear-light resample: source footprint of every destination texel, box-weighted; degenerates to
-    // bilinear interpolation of the two nearest texel centres when magnifying
-    const double sx = (double)w / N, sy = (double)h / N;
-    for (uint32_t y = 0; y < N; ++y)
-        for (uint32_t x = 0; x < N; ++x) {
-            double acc[4] = {0, 0, 0, 0}, wsum = 0;
-            const double x0 = x * sx, x1 = (x + 1) * sx, y0 = y * sy, y1 = (y + 1) * sy;
-            const double fx0 = sx >= 1 ? x0 : (x0 + x1) * 0.5 - 0.5, fx1 = sx >= 1 ? x1 : fx0 + 1.0;
-            const double fy0 = sy >= 1 ? y0 : (y0 + y1) * 0.5 - 0.5, fy1 = sy >= 1 ? y1 : fy0 + 1.0;
-            for (long yy = (long)std::floor(fy0); yy < (long)std::ceil(fy1); ++yy)
-                for (long xx = (long)std::floor(fx0); xx < (long)std::ceil(fx1); ++xx) {
-                    const double wx = std::min(fx1, (double)xx + 1) - std::max(fx0, (double)xx);
-                    const double wy = std::min(fy1, (double)yy + 1) - std::max(fy0, (double)yy);
-                    if (wx <= 0 || wy <= 0) continue;
-                    const long cx = std::min<long>(std::max<long>(xx, 0), (long)w - 1), cy = std::min<long>(std::max<long>(yy, 0), (long)h - 1);
-                    const uint8_t* p = rgba + ((size_t)cy * w + (size_t)cx) * 4;
-                    const double wt = wx * wy;
-                    for (int k = 0; k < 3; ++k) acc[k] += wt * srgb_to_linear(p[k]);
-                    acc[3] += wt * (p[3] / 255.0);
-                    wsum += wt;
-                }
-            uint8_t* d = out + ((size_t)y * N + x) * 4;
-            for (int k = 0; k < 3; ++k) d[k] = linear_to_srgb((float)(acc[k] / wsum));
-            d[3] = (uint8_t)std::lrint(std::min(1.0, std::max(0.0, acc[3] / wsum)) * 255.0);
-        }
-}
 
 rt_scene_desc LoadedScene::desc() const {
     rt_scene_desc d{};
@@ -245,7 +203,7 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
         if (off + len > g.bin.size()) throw std::runtime_error("glTF: image buffer view out of bounds");
         uint32_t w = 0, h = 0;
         std::vector<uint8_t> rgba;
-        decode_png_rgba8(g.bin.data() + off, len, w, h, rgba);
+        decode_image_rgba8(g.bin.data() + off, len, w, h, rgba);
         resize_to_layer(rgba.data(), w, h, sc.textures.data() + i * RT_TEX_SIZE * RT_TEX_SIZE * 4);
         if (verbose) std::printf("Resized image %zu from %ux%u to %ux%u\n", i, w, h, RT_TEX_SIZE, RT_TEX_SIZE);
     }

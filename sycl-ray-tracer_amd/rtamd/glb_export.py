@@ -47,7 +47,9 @@ def _camera_quaternion(direction) -> list[float]:
     return [float(v) for v in q]
 
 
-def export_glb(desc: SceneDesc, path, with_camera: bool = True) -> None:
+def export_glb(desc: SceneDesc, path, with_camera: bool = True, jpeg_quality: int | None = None, texture_size: int | None = None) -> None:
+    """jpeg_quality: embed the textures as JPEG of that quality instead of PNG; texture_size: resample them to that
+    edge length first (so that the loader's decoder and texture baker have real work to do)."""
     from PIL import Image
 
     blob = bytearray()
@@ -90,8 +92,14 @@ def export_glb(desc: SceneDesc, path, with_camera: bool = True) -> None:
     images, textures = [], []
     for layer in range(desc.textures.shape[0]):
         buf = io.BytesIO()
-        Image.fromarray(desc.textures[layer], "RGBA").save(buf, format="PNG")
-        images.append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png"})
+        im = Image.fromarray(desc.textures[layer], "RGBA")
+        if texture_size:
+            im = im.resize((texture_size, texture_size), Image.BICUBIC)
+        if jpeg_quality is None:
+            im.save(buf, format="PNG")
+        else:
+            im.convert("RGB").save(buf, format="JPEG", quality=int(jpeg_quality), subsampling=2)
+        images.append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png" if jpeg_quality is None else "image/jpeg"})
         textures.append({"source": layer})
 
     materials, used_ext = [], set()

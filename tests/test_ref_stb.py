@@ -1,0 +1,189 @@
+"""The loader's image path against the REFERENCE's own decoder and resizer.
+
+oracle/_ref/libref_stb.so is built from the reference's vendored stb_image.h / stb_image_resize2.h where they lie
+under /root/reference (`make -C oracle ref`; recipe and wrapper in oracle/, binary git-ignored). It does exactly what
+the reference does with an embedded glTF image: stbi_load_from_memory(..., 4) (deps/include/tiny_gltf.h:2603-2634)
+and stbir_resize_uint8_srgb(..., 512, 512, 0, STBIR_RGBA) (src/image_manager.hpp:52-62). Skipped where the library
+was never built."""
+import ctypes as C
+import io
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rtamd import abi
+
+REPO = Path(__file__).resolve().parent.parent
+REF = REPO / "oracle" / "_ref" / "libref_stb.so"
+HOST = REPO / "sycl-ray-tracer_amd" / "host" / "build" / "librt_host.so"
+
+pytestmark = pytest.mark.skipif(not REF.exists(), reason="oracle/_ref/libref_stb.so not built (no /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def libs(rtlib):
+    ref, host = C.CDLL(str(REF)), C.CDLL(str(HOST))
+    ref.ref_decode_rgba8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
+    ref.ref_resize_to_layer.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    host.rth_last_error.restype = C.c_char_p
+    host.rth_decode_image.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_size_t]
+    host.rth_resize_to_layer.argtypes = [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    return ref, host
+
+
+def ref_decode(ref, blob: bytes):
+    data = np.frombuffer(blob, np.uint8)
+    w, h = C.c_int(), C.c_int()
+    out = np.zeros(2048 * 2048 * 4, np.uint8)
+    rc = ref.ref_decode_rgba8(abi.u8ptr(data), data.size, C.byref(w), C.byref(h), abi.u8ptr(out), out.size)
+    if rc != 0:
+        return None
+    return out[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
+
+def our_decode(host, blob: bytes):
+    data = np.frombuffer(blob, np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    out = np.zeros(2048 * 2048 * 4, np.uint8)
+    rc = host.rth_decode_image(abi.u8ptr(data), data.size, C.byref(w), C.byref(h), abi.u8ptr(out), out.size)
+    if rc != 0:
+        return None
+    return out[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
+
+def _picture(rng, h, w):
+    """Smooth structure + texture + noise, so that DCT blocks carry low and high frequencies."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    base = np.stack([128 + 100 * np.sin(xx / 17.0) * np.cos(yy / 23.0), 128 + 90 * np.cos((xx + yy) / 11.0),
+                     (xx * 3 + yy * 5) % 256], -1)
+    return np.clip(base + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA", "P"])
+@pytest.mark.parametrize("size", [(67, 91), (1, 1), (64, 64)])
+def test_png_decoder_equals_the_references(libs, mode, size):
+    from PIL import Image
+    ref, host = libs
+    rng = np.random.default_rng(hash((mode, size)) & 0xFFFF)
+    img = rng.integers(0, 256, size + (4,), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img, "RGBA").convert(mode).save(buf, format="PNG")
+    a, r = our_decode(host, buf.getvalue()), ref_decode(ref, buf.getvalue())
+    assert a is not None and r is not None
+    np.testing.assert_array_equal(a, r)
+
+
+@pytest.mark.parametrize("name,shape", [("same", (512, 512)), ("half", (1024, 1024)), ("wide", (512, 1024)), ("odd", (200, 300)),
+                                        ("up", (100, 64)), ("tall", (1000, 700)), ("tiny", (5, 3)), ("one", (1, 1)), ("near", (511, 513))])
+@pytest.mark.parametrize("alpha", [False, True])
+def test_texture_baker_follows_the_references_resize(libs, name, shape, alpha):
+    """512x512 layers as the reference bakes them: identical for 512x512 sources; elsewhere at most 1 LSB away in under
+    1.5 % of the values (stb's table-driven float->sRGB8 step is not restated; everything else is)."""
+    ref, host = libs
+    rng = np.random.default_rng(len(name) * 7 + alpha)
+    img = np.concatenate([_picture(rng, *shape), np.full(shape + (1,), 255, np.uint8)], -1)
+    if name in ("half", "odd"):
+        img[..., :3] = rng.integers(0, 256, shape + (3,), dtype=np.uint8)  # worst case: white noise
+    if alpha:
+        img[..., 3] = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[: max(1, shape[0] // 4), :, 3] = 0  # a fully transparent band
+    img = np.ascontiguousarray(img)
+    a, r = np.zeros((512, 512, 4), np.uint8), np.zeros((512, 512, 4), np.uint8)
+    host.rth_resize_to_layer(abi.u8ptr(img), shape[1], shape[0], abi.u8ptr(a))
+    assert ref.ref_resize_to_layer(abi.u8ptr(img), shape[1], shape[0], abi.u8ptr(r)) == 0
+    d = np.abs(a.astype(np.int32) - r.astype(np.int32))
+    if shape == (512, 512):
+        assert d.max() == 0
+    else:
+        assert d.max() <= 1 and (d > 0).mean() < 0.015
+
+
+JPEG_CASES = [  # (name, size, PIL save options)
+    ("444", (64, 64), dict(quality=90, subsampling=0)),
+    ("422", (77, 53), dict(quality=85, subsampling=1)),
+    ("420", (131, 97), dict(quality=75, subsampling=2)),
+    ("420_q30", (200, 120), dict(quality=30, subsampling=2)),
+    ("420_q100", (48, 80), dict(quality=100, subsampling=2)),
+    ("tiny", (1, 1), dict(quality=90)),
+    ("thin", (3, 40), dict(quality=90, subsampling=2)),
+    ("one_col_chroma", (17, 2), dict(quality=90, subsampling=2)),
+    ("optimised", (120, 90), dict(quality=80, optimize=True)),
+    ("restart_rows", (150, 150), dict(quality=80, subsampling=2, restart_marker_rows=1)),
+    ("restart_blocks", (150, 150), dict(quality=80, subsampling=0, restart_marker_blocks=3)),
+    ("progressive_420", (160, 120), dict(quality=80, subsampling=2, progressive=True)),
+    ("progressive_444", (95, 61), dict(quality=92, subsampling=0, progressive=True)),
+    ("progressive_restart", (130, 130), dict(quality=70, subsampling=1, progressive=True, restart_marker_rows=2)),
+    ("big", (512, 512), dict(quality=88, subsampling=2)),
+]
+
+
+@pytest.mark.parametrize("name,size,opts", JPEG_CASES, ids=[c[0] for c in JPEG_CASES])
+@pytest.mark.parametrize("grey", [False, True])
+def test_jpeg_decoder_equals_the_references(libs, name, size, opts, grey):
+    """Baseline, optimised-Huffman, restart-interval and progressive JPEGs, colour (4:4:4 / 4:2:2 / 4:2:0) and greyscale:
+    every texel equals what the reference's stb_image produces (same IDCT, chroma upsampling and YCbCr arithmetic)."""
+    from PIL import Image
+    ref, host = libs
+    rng = np.random.default_rng(len(name) + 100 * grey)
+    h, w = size[1], size[0]
+    img = Image.fromarray(_picture(rng, h, w), "RGB")
+    if grey:
+        img = img.convert("L")
+        opts = {k: v for k, v in opts.items() if k != "subsampling"}
+    buf = io.BytesIO()
+    img.save(buf, format="JPEG", **opts)
+    a, r = our_decode(host, buf.getvalue()), ref_decode(ref, buf.getvalue())
+    assert r is not None
+    assert a is not None, host.rth_last_error()
+    assert a.shape == (h, w, 4)
+    np.testing.assert_array_equal(a, r)
+    # and both are the picture PIL decodes, up to the usual decoder-to-decoder differences
+    pil = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")).astype(np.int32)
+    assert np.abs(a[..., :3].astype(np.int32) - pil).mean() < (1.5 if min(w, h) >= 16 else 8.0)
+
+
+def test_undecodable_images_are_errors_in_both(libs):
+    ref, host = libs
+    for blob in (b"", b"\xff\xd8\xff", b"\xff\xd8\xff\xe0\x00\x10JFIF\x00" + b"\x00" * 64, b"GIF89a" + b"\x00" * 32, b"\x89PNG\r\n\x1a\n" + b"\x00" * 16):
+        assert our_decode(host, blob) is None
+    # what this loader does not read but stb does is an error here, never a wrong picture: CMYK JPEG
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.new("CMYK", (16, 16), (10, 20, 30, 40)).save(buf, format="JPEG")
+    assert our_decode(host, buf.getvalue()) is None and b"three-component" in host.rth_last_error()
+
+
+def test_glb_with_jpeg_textures_bakes_the_references_layers(libs, scene_cache, tmp_path):
+    """End to end through the C++ loader: a GLB whose textures are 640x640 JPEGs -> decoded and baked to 512x512 layers;
+    each layer is what the reference's stbi_load_from_memory + stbir_resize_uint8_srgb make of the same bytes."""
+    import json
+    import struct
+    from rtamd.glb_export import export_glb
+    from test_host_cpp import CppScene
+    ref, host = libs
+    host.rth_load_glb.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    host.rth_scene_free.argtypes = [C.c_void_p]
+    host.rth_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.rt_scene_desc)]
+    host.rth_scene_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    sd = scene_cache("atrium", detail=1)
+    glb = tmp_path / "jpeg.glb"
+    export_glb(sd, glb, jpeg_quality=85, texture_size=640)
+    cs = CppScene(host, glb)
+    n = cs.c.n_layers
+    assert n == sd.textures.shape[0] and n >= 8
+    layers = np.ctypeslib.as_array(cs.c.textures, (n, 512, 512, 4))
+    raw = glb.read_bytes()
+    jlen = struct.unpack_from("<I", raw, 12)[0]
+    js = json.loads(raw[20:20 + jlen])
+    bin0 = 20 + jlen + 8
+    for i, im in enumerate(js["images"]):
+        assert im["mimeType"] == "image/jpeg"
+        v = js["bufferViews"][im["bufferView"]]
+        blob = raw[bin0 + v["byteOffset"]: bin0 + v["byteOffset"] + v["byteLength"]]
+        dec = ref_decode(ref, blob)
+        assert dec.shape == (640, 640, 4)
+        want = np.zeros((512, 512, 4), np.uint8)
+        assert ref.ref_resize_to_layer(abi.u8ptr(np.ascontiguousarray(dec)), 640, 640, abi.u8ptr(want)) == 0
+        d = np.abs(layers[i].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.015
