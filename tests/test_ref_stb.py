@@ -187,3 +187,17 @@ def test_glb_with_jpeg_textures_bakes_the_references_layers(libs, scene_cache, t
         assert ref.ref_resize_to_layer(abi.u8ptr(np.ascontiguousarray(dec)), 640, 640, abi.u8ptr(want)) == 0
         d = np.abs(layers[i].astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 0.015
+
+
+def test_png_written_by_the_host_adapter_reads_back_in_the_references_decoder(libs, tmp_path):
+    """out.png (src/util.hpp:27 writes it with stbi_write_png): the file this build writes decodes, in the reference's
+    own stb_image, to exactly the RGBA8 frame that was handed to the writer."""
+    ref, host = libs
+    host.rth_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    rng = np.random.default_rng(9)
+    for h, w in ((1, 1), (37, 53), (270, 480)):
+        img = np.ascontiguousarray(rng.integers(0, 256, (h, w, 4), dtype=np.uint8))
+        img[..., 3] = 255
+        path = tmp_path / f"o_{w}x{h}.png"
+        assert host.rth_write_png(str(path).encode(), w, h, abi.u8ptr(img)) == 0
+        np.testing.assert_array_equal(ref_decode(ref, path.read_bytes()), img)
