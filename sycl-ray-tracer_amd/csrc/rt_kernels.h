@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
             if (STATS) ws.live_lane_steps += n_live;
-            (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
         }
         if (STATS) {
             ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
