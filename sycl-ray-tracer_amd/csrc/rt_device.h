@@ -356,11 +356,10 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
     const bool inner = T.cur >= 0;
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
-#ifndef RT_LEAF_NUM
-#define RT_LEAF_NUM 1u
-#define RT_LEAF_DEN 1u
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 64u // with whole-leaf steps: leaf lanes that force a leaf step even against an inner majority
 #endif
-    if (ni * RT_LEAF_NUM >= nl * RT_LEAF_DEN) {
+    if (ni >= nl && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes));
         if (inner) trav_inner(S, T, stack, top);
     } else {
