@@ -117,7 +117,7 @@ struct Hit {
 // Moller-Trumbore on the precomputed (v0, e1, e2); barycentrics in Embree's convention
 // P = (1-u-v) v0 + u v1 + v v2. Edge tests on the sign-corrected numerators; one division per
 // accepted candidate. Minimum t wins, equal t -> lowest global index (order independent).
-RT_DEV void tri_test_regs(float4 a, float4 b, float4 c, f3 o, f3 d, Hit& best) {
+RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) { // the record's 10 live dwords
     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     const uint32_t gidx = __float_as_uint(c.y);
     const f3 p = cross3(d, e2);
@@ -141,7 +141,7 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float4 c, f3 o, f3 d, Hit& best) {
 }
 RT_DEV void tri_test(const TriRec* __restrict__ tr, f3 o, f3 d, Hit& best) {
     const float4* p4 = reinterpret_cast<const float4*>(tr);
-    tri_test_regs(p4[0], p4[1], p4[2], o, d, best);
+    tri_test_regs(p4[0], p4[1], *reinterpret_cast<const float2*>(p4 + 2), o, d, best);
 }
 
 // ---- BVH4 traversal as a resumable per-lane state machine --------------------------------------------
@@ -326,12 +326,14 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
         const float4* p4 = reinterpret_cast<const float4*>(S.tris + first);
-        float4 a = p4[0], b = p4[1], c = p4[2];
+        float4 a = p4[0], b = p4[1];
+        float2 c = *reinterpret_cast<const float2*>(p4 + 2);
         uint32_t k = 1;
         for (; k < 4u; ++k) {
             if (__ballot(k <= rem) == 0ull) break;
-            float4 na = a, nb = b, nc = c;
-            if (k <= rem) na = p4[3 * k], nb = p4[3 * k + 1], nc = p4[3 * k + 2];
+            float4 na = a, nb = b;
+            float2 nc = c;
+            if (k <= rem) na = p4[3 * k], nb = p4[3 * k + 1], nc = *reinterpret_cast<const float2*>(p4 + 3 * k + 2);
             if (k - 1u <= rem) tri_test_regs(a, b, c, T.o, T.d, T.best);
             a = na, b = nb, c = nc;
         }
