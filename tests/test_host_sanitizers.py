@@ -1,0 +1,95 @@
+"""The host loader (GLB container, JSON, accessors, PNG and JPEG decoders, texture baker) under AddressSanitizer + UBSan,
+fed mutated files: truncations, bit flips and spliced garbage must be rejected with an exception or decode to SOMETHING, never
+touch memory they do not own. (CPU only: GPU ASan is not available on this pool.)"""
+import io
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+HOST = REPO / "sycl-ray-tracer_amd" / "host"
+
+
+def test_loader_survives_mutated_files_under_asan_ubsan(tmp_path):
+    from PIL import Image
+    exe = tmp_path / "fuzz_images"
+    srcs = [str(REPO / "tests" / "tools" / "fuzz_images.cpp")] + [str(HOST / f) for f in ("jpeg.cpp", "png.cpp", "texture_resize.cpp", "scene_loader.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", f"-I{HOST}",
+                    f"-I{REPO / 'include'}", "-o", str(exe)] + srcs + ["-lz"], check=True, capture_output=True)
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:48, 0:61]
+    pic = np.stack([(xx * 4) % 256, (yy * 5) % 256, (xx + yy) % 256], -1).astype(np.uint8)
+    seeds = []
+    for opts in (dict(format="JPEG", quality=80, subsampling=2), dict(format="JPEG", quality=90, subsampling=0, progressive=True),
+                 dict(format="JPEG", quality=70, subsampling=1, restart_marker_rows=1), dict(format="PNG")):
+        buf = io.BytesIO()
+        Image.fromarray(pic, "RGB").save(buf, **opts)
+        seeds.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(pic, "RGB").convert("P").save(buf, format="PNG")
+    seeds.append(buf.getvalue())
+    files = []
+    for si, seed in enumerate(seeds):
+        (tmp_path / f"s{si}.bin").write_bytes(seed)
+        files.append(tmp_path / f"s{si}.bin")
+        for k in range(60):
+            b = bytearray(seed)
+            mode = k % 4
+            if mode == 0:  # truncate
+                b = b[: int(rng.integers(1, len(b)))]
+            elif mode == 1:  # flip a few bits, mostly in the headers
+                for _ in range(int(rng.integers(1, 6))):
+                    pos = int(rng.integers(0, min(len(b), 700)))
+                    b[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 2:  # overwrite a run with noise
+                pos = int(rng.integers(0, len(b) - 8))
+                b[pos: pos + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+            else:  # splice two halves of different offsets
+                cut = int(rng.integers(8, len(b) - 8))
+                b = b[:cut] + b[cut + int(rng.integers(1, 8)):]
+            p = tmp_path / f"m{si}_{k}.bin"
+            p.write_bytes(bytes(b))
+            files.append(p)
+    # whole GLB files through load_glb: the shipped cube and a generated scene with textures, camera and extensions
+    import sys
+    sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
+    from rtamd import scenes
+    from rtamd.glb_export import export_glb
+    export_glb(scenes.cornell_scene(), tmp_path / "g1.glb")
+    export_glb(scenes.atrium_scene(1), tmp_path / "g2.glb", jpeg_quality=60, texture_size=32)
+    glbs = [(REPO / "assets" / "cube.glb").read_bytes(), (tmp_path / "g1.glb").read_bytes(), (tmp_path / "g2.glb").read_bytes()]
+    for gi, seed in enumerate(glbs):
+        files.append(tmp_path / f"g{gi}_ok.glb")
+        files[-1].write_bytes(seed)
+        jlen = int.from_bytes(seed[12:16], "little")
+        for k in range(70):
+            b = bytearray(seed)
+            mode = k % 5
+            if mode == 0:
+                b = b[: int(rng.integers(12, len(b)))]
+            elif mode == 1:  # damage the JSON chunk
+                for _ in range(int(rng.integers(1, 4))):
+                    b[20 + int(rng.integers(0, jlen))] = int(rng.integers(32, 127))
+            elif mode == 2:  # change a digit (indices, counts, offsets)
+                digits = [i for i in range(20, 20 + jlen) if 48 <= b[i] <= 57]
+                for _ in range(int(rng.integers(1, 4))):
+                    b[digits[int(rng.integers(0, len(digits)))]] = 48 + int(rng.integers(0, 10))
+            elif mode == 3:  # damage chunk headers / binary payload
+                pos = int(rng.integers(0, 28)) if k % 2 else int(rng.integers(20 + jlen, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            else:  # a huge number somewhere
+                digits = [i for i in range(20, 20 + jlen) if 48 <= b[i] <= 57]
+                i = digits[int(rng.integers(0, len(digits)))]
+                b[i: i + 1] = b"4000000000"
+                b[12:16] = (jlen + 9).to_bytes(4, "little")
+            p = tmp_path / f"g{gi}_{k}.glb"
+            p.write_bytes(bytes(b))
+            files.append(p)
+    env = {"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:allocator_may_return_null=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}
+    p = subprocess.run([str(exe)] + [str(f) for f in files], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-4000:]
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-4000:]
+    print(p.stdout.strip())
+    decoded = int(p.stdout.split()[1])
+    assert decoded >= len(seeds) + len(glbs)  # the unmodified files (and usually many damaged ones) are accepted
