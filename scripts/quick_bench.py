@@ -9,7 +9,7 @@ from rtamd.renderer import Scene, Camera, MegakernelRenderer, WavefrontRenderer
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 detail = int(os.environ.get("DETAIL", "4"))
-W, H = 1920, 1080
+W, H = (int(v) for v in os.environ.get("RES", "1920x1080").split("x"))
 sd = scenes.atrium_scene(detail)
 for bvh, bname in ((abi.RT_BVH_SAH, "sah"),) + (((abi.RT_BVH_LBVH, "lbvh"),) if os.environ.get("LBVH") else ()):
     sc = Scene(sd, 0, bvh)
