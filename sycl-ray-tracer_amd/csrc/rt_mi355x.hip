@@ -37,6 +37,18 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                            \
     } while (0)
 
+// nothing may cross the C ABI as a C++ exception (std::vector growth inside the host orchestration can throw)
+template <typename F>
+int no_throw(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID, std::string("internal error: ") + e.what());
+    }
+}
+
 int device_ok(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -66,9 +78,9 @@ int upload(const std::vector<T>& v, const T** out, uint64_t& bytes) {
     const size_t n = std::max<size_t>(v.size(), 1);
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, n * sizeof(T)));
-    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    *out = (const T*)p;
+    *out = (const T*)p; // owned by the scene from here on: rt_scene_destroy frees it even if the copy fails
     bytes += n * sizeof(T);
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -517,6 +529,9 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
     } catch (const std::bad_alloc&) {
         delete s;
         return fail(RT_ERR_OOM, "host allocation failed while building the scene");
+    } catch (const std::exception& e) { // nothing may cross the C ABI as an exception
+        delete s;
+        return fail(RT_ERR_INVALID, std::string("scene build failed: ") + e.what());
     }
     if (rc != RT_OK) {
         delete s;
@@ -634,7 +649,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
     }
-    rc = alloc_tile_buffers(r);
+    rc = no_throw([&] { return alloc_tile_buffers(r); });
     if (rc != RT_OK) return bail(rc);
     *out = r;
     return RT_OK;
@@ -662,7 +677,7 @@ int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t
     HIPCHK(hipSetDevice(r->scene->device));
     HIPCHK(hipStreamSynchronize(r->stream));
     r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
-    return alloc_tile_buffers(r);
+    return no_throw([&] { return alloc_tile_buffers(r); });
 }
 
 int32_t rt_renderer_local_rows(const rt_renderer* r) { return r ? r->tile.local_rows : 0; }
@@ -688,7 +703,7 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce) {
 
 int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8, rt_stats* stats) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    int rc = render_impl(r, cam, rgba_f32 ? r->d_f32 : nullptr, rgba_u8 ? r->d_u8 : nullptr, r->stream, stats);
+    int rc = no_throw([&] { return render_impl(r, cam, rgba_f32 ? r->d_f32 : nullptr, rgba_u8 ? r->d_u8 : nullptr, r->stream, stats); });
     if (rc != RT_OK) return rc;
     if (rgba_f32 && r->n_local) HIPCHK(hipMemcpy(rgba_f32, r->d_f32, (size_t)r->n_local * 16, hipMemcpyDeviceToHost));
     if (rgba_u8 && r->n_local) HIPCHK(hipMemcpy(rgba_u8, r->d_u8, (size_t)r->n_local * 4, hipMemcpyDeviceToHost));
@@ -698,7 +713,7 @@ int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8
 int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream,
                            rt_stats* stats) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    return render_impl(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream, stats);
+    return no_throw([&] { return render_impl(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream, stats); });
 }
 
 int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out) {
