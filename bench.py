@@ -155,6 +155,14 @@ def main() -> int:
             roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
             roof["note"] = ("the megakernel has no per-ray HBM stream (SURVEY.md §8d): its only algorithmic HBM traffic is the frame store; "
                             "its BVH gathers are served by L2 / Infinity Cache (profiles/r01_traffic.json)")
+        valu_file = REPO / "profiles" / "r01_valu.json"
+        if valu_file.exists():  # what actually bounds the kernel (PMC, measured once per round: rocprofv3 cannot run inside bench.py)
+            v = json.loads(valu_file.read_text()).get(kernel)
+            if v:
+                roof["valu_issue_busy"] = min(1.0, v["valu_issue_busy"])
+                roof["valu_lane_utilisation"] = v["lane_utilisation"]
+                roof["valu_note"] = ("SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * kernel cycles) and SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) "
+                                     "from profiles/r01_valu.json: the kernel is bound by VALU issue at this lane utilisation, not by HBM")
         traffic_file = REPO / "profiles" / "r01_traffic.json"
         if traffic_file.exists() and (W, H) == (1920, 1080) and world == 1:
             t = json.loads(traffic_file.read_text()).get(kernel)  # PMC-measured (rocprofv3 cannot run inside bench.py)
