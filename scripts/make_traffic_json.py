@@ -1,12 +1,13 @@
 """profiles/r01_traffic.json from the counter CSVs of four rocprofv3 passes (scripts/pmc_pass.sh):
    python3 scripts/make_traffic_json.py gpurun_out/pmc_<tag>_{fetch,write,hit,miss}...  (any directories; all CSVs are merged)."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
 rays = None
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun merges runs into the same directory: only the newest pass counts
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
             m = re.search(r"rt::(k_\w+)", k)
