@@ -10,6 +10,7 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -584,6 +585,59 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     // Emission order: breadth-first until the LDS-staged top of the tree is complete (the first nodes of the
     // array are the shallowest ones), depth-first below it, so that the nodes and the triangles of one
     // subtree are contiguous in memory (fewer distinct cache lines per ray than a pure breadth-first layout).
+    // Which binary nodes become BVH4 nodes: dynamic programme over the binary tree (after Ylitie, Karras, Laine 2017).
+    // best[n][k] = least SAH cost of covering subtree n with at most k child slots of its BVH4 parent; a subtree that
+    // takes one slot is a leaf or a BVH4 node of its own (area + the best way to hand its 4 slots to its two halves).
+    // cut[n][4] = slots a BVH4 node n gives to its LEFT half. RT_BVH_COLLAPSE=greedy restores the open-the-largest-child rule.
+    bool use_dp = true;
+    if (const char* e = std::getenv("RT_BVH_COLLAPSE")) use_dp = std::string(e) != "greedy";
+    std::vector<std::array<float, 5>> best;
+    std::vector<std::array<uint8_t, 5>> cut;
+    if (use_dp) {
+        best.assign(b.nodes.size(), {}), cut.assign(b.nodes.size(), {});
+        std::vector<int32_t> post, st{0};
+        while (!st.empty()) { // pre-order, reversed = children before parents
+            const int32_t i = st.back();
+            st.pop_back();
+            post.push_back(i);
+            if (b.nodes[i].left >= 0) st.push_back(b.nodes[i].left), st.push_back(b.nodes[i].right);
+        }
+        for (size_t q = post.size(); q-- > 0;) {
+            const int32_t i = post[q];
+            const GNode& g = b.nodes[i];
+            const float ar = half_area(g.lo, g.hi);
+            if (g.left < 0) {
+                for (int k = 1; k <= 4; ++k) best[i][k] = ar * (float)g.count;
+                continue;
+            }
+            float dist[5];
+            uint8_t dl[5];
+            for (int k = 2; k <= 4; ++k) {
+                dist[k] = std::numeric_limits<float>::infinity(), dl[k] = 1;
+                for (int l = 1; l < k; ++l) {
+                    const float c = best[g.left][l] + best[g.right][k - l];
+                    if (c < dist[k]) dist[k] = c, dl[k] = (uint8_t)l;
+                }
+            }
+            best[i][1] = ar + dist[4];
+            for (int k = 2; k <= 4; ++k) best[i][k] = std::min(dist[k], best[i][k - 1]);
+            cut[i][4] = dl[4]; // what the node does with its OWN four slots when it is a BVH4 node (best[i][1])
+        }
+    }
+    // children of BVH4 node: expand the recorded decisions (subtree n may use up to k slots)
+    std::function<void(int32_t, int, int32_t*, int&)> gather = [&](int32_t n, int k, int32_t* kids, int& nk) {
+        const GNode& g = b.nodes[n];
+        if (k <= 1 || g.left < 0) { kids[nk++] = n; return; }
+        // as a PARENT's subtree with k slots: either distribute them or fall back to k-1
+        float dist = std::numeric_limits<float>::infinity();
+        int dl = 1;
+        for (int l = 1; l < k; ++l) {
+            const float c = best[g.left][l] + best[g.right][k - l];
+            if (c < dist) dist = c, dl = l;
+        }
+        if (dist < best[n][k - 1]) gather(g.left, dl, kids, nk), gather(g.right, k - dl, kids, nk);
+        else gather(n, k - 1, kids, nk);
+    };
     constexpr size_t kBfsNodes = 341;
     q.push_back({0, 0, 0});
     while (!q.empty()) {
@@ -594,20 +648,26 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         cost += (double)half_area(g.lo, g.hi) / root_area;
         int32_t kids[4] = {g.left, g.right, -1, -1};
         int nk = 2;
-        while (nk < 4) {
-            int best = -1;
-            float best_area = -1.0f;
-            for (int k = 0; k < nk; ++k) {
-                const GNode& c = b.nodes[kids[k]];
-                if (c.left >= 0) {
-                    float ar = half_area(c.lo, c.hi);
-                    if (ar > best_area) best_area = ar, best = k;
+        if (use_dp) {
+            nk = 0;
+            const int li = cut[it.gnode][4];
+            gather(g.left, li, kids, nk), gather(g.right, 4 - li, kids, nk);
+        } else {
+            while (nk < 4) { // greedy: open the inner child with the largest surface area
+                int best = -1;
+                float best_area = -1.0f;
+                for (int k = 0; k < nk; ++k) {
+                    const GNode& c = b.nodes[kids[k]];
+                    if (c.left >= 0) {
+                        float ar = half_area(c.lo, c.hi);
+                        if (ar > best_area) best_area = ar, best = k;
+                    }
                 }
+                if (best < 0) break;
+                const GNode& c = b.nodes[kids[best]];
+                kids[best] = c.left;
+                kids[nk++] = c.right;
             }
-            if (best < 0) break;
-            const GNode& c = b.nodes[kids[best]];
-            kids[best] = c.left;
-            kids[nk++] = c.right;
         }
         BvhNode out = empty_node();
         Item pending[4];
