@@ -638,7 +638,10 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         if (dist < best[n][k - 1]) gather(g.left, dl, kids, nk), gather(g.right, k - dl, kids, nk);
         else gather(n, k - 1, kids, nk);
     };
-    constexpr size_t kBfsNodes = 341;
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 341 // must equal rt_device.h's: the nodes the traversal kernels stage in LDS
+#endif
+    constexpr size_t kBfsNodes = RT_TOP_NODES;
     q.push_back({0, 0, 0});
     while (!q.empty()) {
         Item it;
