@@ -100,10 +100,10 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #define RT_MEGA_WAVES 6
 #endif
 #ifndef RT_MEGA_REFILL
-#define RT_MEGA_REFILL 8u // idle lanes that trigger a pixel fetch
+#define RT_MEGA_REFILL 1u // idle lanes that trigger a pixel fetch (re-tuned with whole-leaf steps: 8 -> 1, +2 %)
 #endif
 #ifndef RT_MEGA_SHADE_PCT
-#define RT_MEGA_SHADE_PCT 50u // shade when this share of the live lanes is waiting
+#define RT_MEGA_SHADE_PCT 80u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %)
 #endif
 #ifndef RT_MEGA_TAIL_SHADE_PCT
 #define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
