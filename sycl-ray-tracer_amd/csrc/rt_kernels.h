@@ -108,6 +108,10 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_TAIL_SHADE_PCT
 #define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
 #endif
+#ifndef RT_MEGA_PRIO
+#define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
+                       // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
+#endif
 #ifndef RT_MEGA_BLOCK
 #define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
 #endif
@@ -118,6 +122,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                                                     unsigned long long* __restrict__ ray_counter,
                                                     unsigned long long* __restrict__ stats_out) {
     WaveStats ws;
+#if RT_MEGA_PRIO == 3
+    if ((threadIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(2); // the block's waves 4..7: the second wave on each SIMD
+#endif
     long long t_begin = 0, t_mark = 0, t_trav = 0, t_shade = 0;
     if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
     const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
@@ -192,6 +199,11 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             t_trav += now - t_mark, t_mark = now;
         }
         // SHADE the lanes whose traversal is complete
+#if RT_MEGA_PRIO == 1
+        __builtin_amdgcn_s_setprio(2);
+#elif RT_MEGA_PRIO == 2 || RT_MEGA_PRIO == 4 || RT_MEGA_PRIO == 5
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (live && T.cur == kTravDone) {
             f3 res;
             rays++;
@@ -219,6 +231,15 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             if (live) trav_begin(T, r.org, ray_dir(r));
         }
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
+#if RT_MEGA_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif RT_MEGA_PRIO == 2
+        __builtin_amdgcn_s_setprio(2);
+#elif RT_MEGA_PRIO == 4
+        __builtin_amdgcn_s_setprio(3);
+#elif RT_MEGA_PRIO == 5
+        __builtin_amdgcn_s_setprio(1);
+#endif
     }
     const uint32_t total = wave_sum_u32(rays);
     if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
@@ -284,6 +305,9 @@ __global__ void __launch_bounds__(256) k_wf_generate(const CameraDev* __restrict
 #ifndef RT_EXTEND_CHUNK
 #define RT_EXTEND_CHUNK 128
 #endif
+#ifndef RT_EXTEND_PRIO
+#define RT_EXTEND_PRIO 0
+#endif
 #ifndef RT_EXTEND_REFILL
 #define RT_EXTEND_REFILL 16
 #endif
@@ -300,6 +324,9 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
                                                                     const uint32_t* __restrict__ count_in,
                                                                     uint32_t* __restrict__ cursor,
                                                                     unsigned long long* __restrict__ stats_out) {
+#if RT_EXTEND_PRIO
+    __builtin_amdgcn_s_setprio(RT_EXTEND_PRIO); // against the other stream's SHADE waves on the same SIMD
+#endif
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
