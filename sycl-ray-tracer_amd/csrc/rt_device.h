@@ -404,6 +404,15 @@ RT_DEV float schlick(float cosine, float ref_idx) {
     float x5 = (x2 * x2) * x;
     return r0 + (1.0f - r0) * x5;
 }
+// b / 255.0f for b = 0..255 without the ten-instruction IEEE division: one Newton step on b * RN(1/255) with exact
+// remainders (two fmas) is correctly rounded for all 256 inputs (enumerated: tests/test_oracle.py, and bit for bit
+// through a texture that holds every value in tests/test_gpu_parity.py)
+RT_DEV float unorm8_to_float(uint32_t b) {
+    const float x = (float)b, r = 1.0f / 255.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
 // Texture::sample (src/material.hpp:45-53): constant colour, or nearest / repeat / normalised
 // fetch from layer tex_layer of the 512x512 RGBA8 array (sampler: src/render_wavefront.cpp:193-197)
 RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
@@ -416,8 +425,7 @@ RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
     iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
     const uint32_t texel = *reinterpret_cast<const uint32_t*>(
         S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u);
-    return mk3((float)(texel & 0xffu) / 255.0f, (float)((texel >> 8) & 0xffu) / 255.0f,
-               (float)((texel >> 16) & 0xffu) / 255.0f);
+    return mk3(unorm8_to_float(texel & 0xffu), unorm8_to_float((texel >> 8) & 0xffu), unorm8_to_float((texel >> 16) & 0xffu));
 }
 
 // Material::scatter (src/material.hpp:211-224) with the three material bodies (:72-86, :98-110,

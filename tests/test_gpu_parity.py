@@ -522,3 +522,29 @@ def test_wavefront_frame_replayed_as_a_hip_graph_is_identical(oracle, scene_cach
         np.testing.assert_array_equal(fr.rgba_u8, b)
     r.close()
     gs.close()
+
+
+def test_every_texel_value_shades_identically(oracle):
+    """A camera-facing quad with a texture that holds every byte value in every channel, lit by the sky only: each pixel
+    is albedo(texel) x sky after one diffuse bounce, so any difference in the texel -> float conversion would show."""
+    sb = scenes.SceneBuilder("texels")
+    iu, iv = np.meshgrid(np.arange(512), np.arange(512), indexing="xy")
+    tex = np.stack([iu % 256, iv % 256, (iu // 2 + iv // 2) % 256, np.full_like(iu, 255)], -1).astype(np.uint8)
+    layer = sb.add_texture(tex)
+    mat = sb.add_material(scenes.Material(abi.RT_MAT_DIFFUSE, (1.0, 1.0, 1.0), layer))
+    sb.add_instance(sb.add_mesh(*scenes.mesh_quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), nx=1, ny=1)), mat)
+    sb.sky = np.array([1.0, 0.75, 0.5], np.float32)
+    sb.camera = scenes.CameraPose((0.0, 0.0, 2.0), (0.0, 0.0, -1.0), 2.0)
+    sd = sb.build()
+    gs, osc = Scene(sd, 0), oracle.OracleScene(sd)
+    w = h = 512
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    for cls, kind in KINDS:
+        r = cls(gs, (w, h), 2, 2)
+        fr = r.render_frame(Camera.for_scene(sd, (w, h)))
+        f, b, rays = osc.render(ocam, kind, 2, 2, use_bvh=False)
+        assert fr.rays == rays
+        np.testing.assert_array_equal(fr.rgba_f32, f)
+        assert len(np.unique(np.round(fr.rgba_f32[..., 0] ** 2 * 255 * 2).astype(int))) > 200  # many distinct albedos were seen
+        r.close()
+    gs.close()

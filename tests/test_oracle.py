@@ -325,3 +325,17 @@ def test_russian_roulette_extension_is_off_by_default_and_unbiased(oracle, scene
         f2, _, r2 = osc.render(cam, kind, 10, 4, rr_start=10)
         f3, _, r3 = osc.render(cam, kind, 10, 4)
         assert r2 == r3 and np.array_equal(f2, f3)
+
+
+def test_texel_division_shortcut_is_exact_for_every_byte():
+    """The kernels compute texel / 255 as one Newton step on b * RN(1/255) (rt_device.h unorm8_to_float): the same float
+    as the IEEE division the oracle performs, for all 256 bytes (fma emulated in float64, which holds every product
+    and sum here exactly)."""
+    x = np.arange(256, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(255.0)
+    q = (x * r).astype(np.float32)
+    rem = x.astype(np.float64) - q.astype(np.float64) * 255.0            # fma(-q, 255, x): exact
+    assert np.array_equal(rem.astype(np.float32).astype(np.float64), rem)  # ... and representable in binary32
+    got = (q.astype(np.float64) + rem * np.float64(r)).astype(np.float32)  # fma(rem, r, q)
+    np.testing.assert_array_equal(got, x / np.float32(255.0))
+    assert (x * r != x / np.float32(255.0)).sum() > 100  # the plain product would NOT do
