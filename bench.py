@@ -55,6 +55,9 @@ def main() -> int:
     ap.add_argument("--detail", type=int, default=4, help="atrium tessellation (4 = ~281k triangles)")
     ap.add_argument("--bvh", choices=["sah", "lbvh"], default="sah")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="frames enqueued at once, each in its own renderer and strip buffer (1 = the reference's one frame at a "
+                         "time; 2 hides the end-of-frame drain of the per-pixel sample chains behind the next frame)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
     args = ap.parse_args()
 
@@ -90,8 +93,9 @@ def main() -> int:
     scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
     cam = Camera.for_scene(sd, (W, H))
     from rtamd.dist import FrameGatherer
-    fg = FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist)
-    local = fg.local
+    F = max(1, args.frames_in_flight)
+    fgs = [FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist) for _ in range(F)]  # one strip buffer per frame in flight
+    fg = fgs[0]
 
     def barrier():
         if use_dist:
@@ -102,31 +106,47 @@ def main() -> int:
         """W warm-up frames, then exactly K timed frames of one renderer: render this rank's strips, RCCL gather,
         de-interleave on rank 0; barrier + synchronize on both sides; MAX over ranks of the time, SUM of the rays."""
         cls = WavefrontRenderer if name == "wavefront" else MegakernelRenderer
-        r = cls(scene, (W, H), args.depth, args.spp)
-        r.set_tile(rank, world, strip)
-        r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the launch's own stream
-        assert fg.rows == r.local_rows
+        rs = [cls(scene, (W, H), args.depth, args.spp) for _ in range(F)]
+        for r in rs:
+            r.set_tile(rank, world, strip)
+            r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the launch's own stream
+        assert fg.rows == rs[0].local_rows
+        tot = {"rays": 0, "hot_ms": 0.0, "hot_launches": 0, "dev_ms": 0.0}
 
-        def step():
-            fr = r.render_frame_device(cam, d_f32=local.data_ptr())
-            fg.gather()  # RCCL gather of the per-GPU strip buffers + de-interleave on rank 0
-            return fr
+        def collect(k):
+            """wait for frame buffer k's frame, gather it (RCCL gather of the per-GPU strip buffers + de-interleave on rank 0)"""
+            fr = rs[k].end_frame()
+            fgs[k].gather()
+            tot["rays"] += fr.rays
+            tot["hot_ms"] += fr.hot_kernel_ms
+            tot["hot_launches"] += fr.hot_kernel_launches
+            tot["dev_ms"] += fr.device_ms
 
-        for _ in range(args.warmup):
-            step()
+        def run(n):
+            """n frames; with --frames-in-flight F > 1 frame i+1..i+F-1 are already enqueued (each in its own renderer and
+            strip buffer) while frame i finishes and is gathered: the next frame's waves fill the end-of-frame drain"""
+            queue = []
+            for i in range(n):
+                k = i % F
+                if len(queue) == F:
+                    collect(queue.pop(0))
+                rs[k].begin_frame(cam, d_f32=fgs[k].local.data_ptr())
+                queue.append(k)
+            while queue:
+                collect(queue.pop(0))
+
+        run(args.warmup)
         barrier()
+        for key in tot:
+            tot[key] = 0
         t0 = time.perf_counter()
-        rays, hot_ms, hot_launches, dev_ms = 0, 0.0, 0, 0.0
-        for _ in range(args.steps):
-            fr = step()
-            rays += fr.rays
-            hot_ms += fr.hot_kernel_ms
-            hot_launches += fr.hot_kernel_launches
-            dev_ms += fr.device_ms
+        run(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        rows = r.local_rows
-        r.close()
+        rays, hot_ms, hot_launches, dev_ms = tot["rays"], tot["hot_ms"], tot["hot_launches"], tot["dev_ms"]
+        rows = rs[0].local_rows
+        for r in rs:
+            r.close()
         rays_all = float(rays)
         if use_dist:
             mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -185,7 +205,7 @@ def main() -> int:
             "warmup": args.warmup, "ms_per_step": best["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}",
-                       "renderer": best["renderer"], "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}",
+                       "renderer": best["renderer"], "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}", "frames_in_flight": F,
                        "rays_per_frame": best["rays_per_frame"]},
             "roofline": best["roofline"],
             "device_ms_per_step": best["device_ms_per_step"],

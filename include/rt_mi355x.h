@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -209,6 +209,13 @@ int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8
  * completed on the device (stats need the ray counter). */
 int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32,
                            void* d_rgba_u8, void* stream, rt_stats* stats);
+
+/* The same frame in two calls: _begin enqueues it on `stream` (NULL = the renderer's own) and returns at once, _end waits
+ * for it and fills `stats`. One frame per renderer may be in flight; frames of DIFFERENT renderers overlap on the device,
+ * which is how a caller hides the end-of-frame drain (the last pixels' sequential samples) behind the next frame.
+ * No reference counterpart (the reference blocks after every kernel: src/render_wavefront.cpp:396-431). */
+int rt_render_frame_begin(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream);
+int rt_render_frame_end(rt_renderer* r, rt_stats* stats);
 
 /* ---- Device unit probes (parity tests of the building blocks; tiny launches) --------------- */
 /* XorShift32State::operator() (src/xorshift.hpp:11-20) run on the device: n draws from `seed`. */

@@ -405,7 +405,7 @@ RT_DEV float schlick(float cosine, float ref_idx) {
     return r0 + (1.0f - r0) * x5;
 }
 // b / 255.0f for b = 0..255 without the ten-instruction IEEE division: one Newton step on b * RN(1/255) with exact
-// remainders (two fmas) is correctly rounded for all 256 inputs (enumerated: tests/test_oracle.py, and bit for bit
+// remainders (two fmas) is correctly rounded for all 256 inputs (enumerated in the CPU tests, and checked bit for bit
 // through a texture that holds every value in tests/test_gpu_parity.py)
 RT_DEV float unorm8_to_float(uint32_t b) {
     const float x = (float)b, r = 1.0f / 255.0f;

@@ -144,6 +144,12 @@ struct rt_renderer {
     hipStream_t graph_stream = nullptr;
     uint32_t graph_launches = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // the frame between rt_render_frame_begin and rt_render_frame_end
+    bool frame_pending = false;
+    hipStream_t pending_stream = nullptr;
+    rt_stats pending_stats{};
+    size_t pending_hot = 0;
+    std::chrono::high_resolution_clock::time_point pending_t0{};
     bool profile_kernels = false;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -396,20 +402,36 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
     return RT_OK;
 }
 
-int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats) {
+// A frame is enqueued (frame_begin) and collected (frame_end) separately, so that a caller can keep a second frame
+// of ANOTHER renderer in flight meanwhile: its persistent waves move in as this frame's last pixels drain.
+int frame_begin(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st) {
     if (!r || !cam) return fail(RT_ERR_INVALID, "null renderer or camera");
+    if (r->frame_pending) return fail(RT_ERR_INVALID, "the renderer's previous frame has not been collected (rt_render_frame_end)");
     if (cam->width != r->width || cam->height != r->height) return fail(RT_ERR_INVALID, "camera size differs from the renderer's image size");
     HIPCHK(hipSetDevice(r->scene->device));
-    rt_stats local{};
-    size_t n_hot = 0;
-    const auto t0 = std::chrono::high_resolution_clock::now();
+    r->pending_stats = rt_stats{};
+    r->pending_hot = 0;
+    r->pending_t0 = std::chrono::high_resolution_clock::now();
     HIPCHK(hipEventRecord(r->ev_begin, st));
-    int rc = enqueue_frame(r, cam, d_f32, d_u8, st, &local, &n_hot);
+    int rc = enqueue_frame(r, cam, d_f32, d_u8, st, &r->pending_stats, &r->pending_hot);
     if (rc != RT_OK) return rc;
     HIPCHK(hipEventRecord(r->ev_end, st));
+    r->pending_stream = st;
+    r->frame_pending = true;
+    return RT_OK;
+}
+
+int frame_end(rt_renderer* r, rt_stats* stats) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    if (!r->frame_pending) return fail(RT_ERR_INVALID, "no frame in flight (rt_render_frame_begin)");
+    HIPCHK(hipSetDevice(r->scene->device));
+    hipStream_t st = r->pending_stream;
+    rt_stats local = r->pending_stats;
+    const size_t n_hot = r->pending_hot;
+    r->frame_pending = false;
     HIPCHK(hipStreamSynchronize(st));
     const auto t1 = std::chrono::high_resolution_clock::now();
-    local.seconds = std::chrono::duration<double>(t1 - t0).count();
+    local.seconds = std::chrono::duration<double>(t1 - r->pending_t0).count();
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
     local.device_ms = ms;
@@ -464,6 +486,11 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
     }
     if (stats) *stats = local;
     return RT_OK;
+}
+
+int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats) {
+    const int rc = frame_begin(r, cam, d_f32, d_u8, st);
+    return rc != RT_OK ? rc : frame_end(r, stats);
 }
 
 } // namespace
@@ -658,6 +685,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
 void rt_renderer_destroy(rt_renderer* r) {
     if (!r) return;
     if (r->scene && hipSetDevice(r->scene->device) == hipSuccess) {
+        if (r->frame_pending && r->pending_stream) (void)hipStreamSynchronize(r->pending_stream);
         if (r->stream) (void)hipStreamSynchronize(r->stream);
         free_tile_buffers(r);
         if (r->d_cam) (void)hipFree(r->d_cam);
@@ -674,6 +702,7 @@ void rt_renderer_destroy(rt_renderer* r) {
 int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t strip_rows) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
     if (world == 0 || rank >= world || strip_rows == 0) return fail(RT_ERR_INVALID, "bad tile split");
+    if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     HIPCHK(hipSetDevice(r->scene->device));
     HIPCHK(hipStreamSynchronize(r->stream));
     r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
@@ -714,6 +743,16 @@ int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f3
                            rt_stats* stats) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
     return no_throw([&] { return render_impl(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream, stats); });
+}
+
+int rt_render_frame_begin(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    return no_throw([&] { return frame_begin(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream); });
+}
+
+int rt_render_frame_end(rt_renderer* r, rt_stats* stats) {
+    if (!r) return fail(RT_ERR_INVALID, "null renderer");
+    return no_throw([&] { return frame_end(r, stats); });
 }
 
 int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out) {

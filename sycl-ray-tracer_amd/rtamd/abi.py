@@ -121,6 +121,8 @@ PROTOTYPES = {
     "rt_renderer_global_row": (C.c_int32, [C.c_void_p, C.c_int32]),
     "rt_renderer_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_renderer_set_russian_roulette": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_render_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_render_frame_end": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_render_frame": (C.c_int, [C.c_void_p, _P(rt_camera), _P(C.c_float), _P(C.c_uint8), _P(rt_stats)]),
     "rt_render_frame_device": (C.c_int, [C.c_void_p, _P(rt_camera), C.c_void_p, C.c_void_p, C.c_void_p,
                                          _P(rt_stats)]),

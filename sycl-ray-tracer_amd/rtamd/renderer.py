@@ -158,6 +158,17 @@ class IRenderer:
         return Frame(None, None, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches),
                      int(st.launches))
 
+    def begin_frame(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> None:
+        """Enqueues the frame and returns at once; collect it with end_frame(). Frames of different renderers overlap on
+        the device (the next frame's waves move in while this one's last pixels drain)."""
+        abi.check(self._lib.rt_render_frame_begin(self.h, C.byref(camera.c), C.c_void_p(d_f32 or None), C.c_void_p(d_u8 or None),
+                                                  C.c_void_p(stream or None)))
+
+    def end_frame(self) -> Frame:
+        st = abi.rt_stats()
+        abi.check(self._lib.rt_render_frame_end(self.h, C.byref(st)))
+        return Frame(None, None, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches), int(st.launches))
+
     def close(self):
         if self.h:
             self._lib.rt_renderer_destroy(self.h)

@@ -548,3 +548,37 @@ def test_every_texel_value_shades_identically(oracle):
         assert len(np.unique(np.round(fr.rgba_f32[..., 0] ** 2 * 255 * 2).astype(int))) > 200  # many distinct albedos were seen
         r.close()
     gs.close()
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_frames_of_two_renderers_in_flight_at_once(oracle, scene_cache, cls, kind):
+    """rt_render_frame_begin / _end: two renderers (double buffering) keep a frame each in flight; every frame is the
+    frame the blocking call renders, in any interleaving, and misuse is an error rather than a hang."""
+    import torch
+    sd = scene_cache("cornell")
+    gs = Scene(sd, 0)
+    w, h = 128, 96
+    cam = Camera.for_scene(sd, (w, h))
+    a, b = cls(gs, (w, h), 6, 4), cls(gs, (w, h), 6, 4)
+    ref = a.render_frame(cam)
+    bufs = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    rs = [a, b]
+    pending = None
+    for i in range(6):
+        r = rs[i % 2]
+        bufs[i % 2].zero_()
+        torch.cuda.synchronize()
+        r.begin_frame(cam, d_f32=bufs[i % 2].data_ptr())
+        if pending is not None:
+            fr = rs[pending].end_frame()
+            assert fr.rays == ref.rays
+            np.testing.assert_array_equal(bufs[pending].cpu().numpy(), ref.rgba_f32)
+        pending = i % 2
+    with pytest.raises(RuntimeError, match="not been collected"):
+        rs[pending].begin_frame(cam, d_f32=bufs[pending].data_ptr())
+    fr = rs[pending].end_frame()
+    assert fr.rays == ref.rays
+    np.testing.assert_array_equal(bufs[pending].cpu().numpy(), ref.rgba_f32)
+    with pytest.raises(RuntimeError, match="no frame in flight"):
+        a.end_frame()
+    a.close(), b.close(), gs.close()
