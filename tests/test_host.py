@@ -187,3 +187,26 @@ def test_atrium_generator_is_deterministic():
         np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
     assert 10_000 < a.n_triangles < 30_000
     assert a.textures.shape[0] == 9
+
+
+def test_builder_stages_keep_the_tree_valid_and_do_not_raise_its_cost(rtlib, scene_cache, monkeypatch):
+    """The two post-passes of the SAH builder — insertion-based optimisation of the binary tree and the dynamic-programming
+    collapse to four children — each leave a structurally valid BVH (every decoded box contains its subtree) and a
+    surface-area cost no higher than without them; RT_BVH_REINSERT=0 / RT_BVH_COLLAPSE=greedy switch them off."""
+    sd = scene_cache("atrium", detail=2)
+    cost = {}
+    for reinsert in ("0", "1", "2"):
+        for collapse in ("greedy", "dp"):
+            monkeypatch.setenv("RT_BVH_REINSERT", reinsert)
+            monkeypatch.setenv("RT_BVH_COLLAPSE", collapse)
+            hs, _c = _host_scene(rtlib, sd, abi.RT_BVH_SAH)
+            assert rtlib.rt_scene_check_bvh(hs) == abi.RT_OK, rtlib.rt_last_error()
+            info = abi.rt_scene_info_t()
+            assert rtlib.rt_scene_info(hs, C.byref(info)) == abi.RT_OK
+            assert info.n_triangles == sd.n_triangles and 1 <= info.max_leaf_tris <= 4
+            cost[reinsert, collapse] = (info.sah_cost, info.n_nodes)
+            rtlib.rt_scene_destroy(hs)
+    assert cost["0", "dp"][0] < cost["0", "greedy"][0] and cost["0", "dp"][1] < cost["0", "greedy"][1]
+    assert cost["1", "greedy"][0] < cost["0", "greedy"][0]
+    assert cost["1", "dp"][0] < cost["0", "greedy"][0]
+    assert cost["2", "dp"][0] < 1.01 * cost["1", "dp"][0]
