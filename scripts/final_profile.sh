@@ -11,7 +11,7 @@ echo ktrace done
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "hit TCC_HIT_sum" "miss TCC_MISS_sum"; do
   set -- $pass
   for rend in wavefront megakernel; do
-    timeout -k 5 150 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/final/pmc_${rend}_$1 -- python3 bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline --renderer $rend > gpurun_out/final/pmc_${rend}_$1.log 2>&1
+    timeout -k 5 150 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/final/pmc_${rend}_$1 -- python3 bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline --no-pipelined --renderer $rend > gpurun_out/final/pmc_${rend}_$1.log 2>&1
     echo "pmc $rend $1 rc=$?"
   done
 done
