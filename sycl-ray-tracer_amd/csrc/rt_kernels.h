@@ -130,6 +130,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
 #endif
     long long t_begin = 0, t_mark = 0, t_trav = 0, t_shade = 0;
     if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
+    unsigned long long wall_begin = 0, wall_exhausted = 0;
+    if (STATS) wall_begin = wall_clock64(); // 100 MHz, the same counter on every CU
     const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)(threadIdx.x & 63u);
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 if (base + cnt >= region_slots) { // this region is used up: move on to the next one
                     region = (region + 1u) & 7u;
                     exhausted = ++regions_done >= 8u;
+                    if (STATS && exhausted) wall_exhausted = wall_clock64();
                 }
             }
         }
@@ -260,6 +263,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         const unsigned long long dur = (unsigned long long)((long long)__builtin_readcyclecounter() - t_begin);
         atomicAdd(stats_out + 8, dur), atomicMax(stats_out + 9, dur), atomicAdd(stats_out + 10, 1ull);
         atomicAdd(stats_out + 11, (unsigned long long)t_trav), atomicAdd(stats_out + 12, (unsigned long long)t_shade);
+        // frame timeline on the chip-wide 100 MHz clock: first wave start, first wave that found the pixel queue empty, last wave end
+        atomicMin(stats_out + 13, wall_begin);
+        if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
+        atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
     }
 }
 
