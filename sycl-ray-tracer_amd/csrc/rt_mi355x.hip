@@ -152,6 +152,9 @@ struct rt_renderer {
     std::chrono::high_resolution_clock::time_point pending_t0{};
     bool profile_kernels = false;
     std::vector<hipEvent_t> ev_pool;
+    // diagnostics (scripts/occupancy_probe.py): RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
+    // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
+    uint32_t mega_lds_pad = 0, mega_occ = RT_MEGA_WAVES;
 };
 
 namespace {
@@ -350,7 +353,12 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
         constexpr uint32_t mega_wpb = RT_MEGA_BLOCK / 64;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
-                                                                        (uint32_t)r->n_cus * 4u * RT_MEGA_WAVES / mega_wpb));
+                                                                        (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
+        const uint32_t pad = r->mega_lds_pad;
+        if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+        }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
         HIPCHK(hipEventRecord(e0, st));
@@ -360,10 +368,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
             HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(RT_MEGA_BLOCK), 0, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(RT_MEGA_BLOCK), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
@@ -666,6 +674,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
                    : (kind == RT_RENDERER_MEGAKERNEL ? RT_SEED_MEGAKERNEL : RT_SEED_WAVEFRONT);
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
+    if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
+    if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
         return code;

@@ -44,7 +44,23 @@ struct Json {
         const Json* j = find(key);
         return j && j->kind == Number ? j->num : dflt;
     }
-    int int_or(const std::string& key, int dflt) const { return (int)number_or(key, (double)dflt); }
+    // the casts below are undefined for NaN / out-of-range doubles, and every number here comes from an untrusted file
+    int int_or(const std::string& key, int dflt) const {
+        const double v = number_or(key, (double)dflt);
+        if (!(v >= -2147483648.0 && v <= 2147483647.0)) throw std::runtime_error("glTF: '" + key + "' is not a valid integer");
+        return (int)v;
+    }
+    // a byte offset / count / index: finite, non-negative, at most `limit`
+    size_t size_or(const std::string& key, size_t dflt, size_t limit) const {
+        const Json* j = find(key);
+        if (!j || j->kind != Number) return dflt;
+        if (!(j->num >= 0.0 && j->num <= (double)limit)) throw std::runtime_error("glTF: '" + key + "' out of range");
+        return (size_t)j->num;
+    }
+    size_t index_value(size_t limit) const { // this number as an index < limit
+        if (kind != Number || !(num >= 0.0 && num < (double)limit)) throw std::runtime_error("glTF: index out of range");
+        return (size_t)num;
+    }
 };
 
 class JsonParser {
@@ -60,6 +76,15 @@ class JsonParser {
   private:
     const std::string& s_;
     size_t p_ = 0;
+    int depth_ = 0; // nesting of arrays / objects: a file of "[[[[..." must not overflow the stack
+    static constexpr int kMaxDepth = 256;
+    struct Nest {
+        JsonParser& p;
+        explicit Nest(JsonParser& q) : p(q) {
+            if (++p.depth_ > kMaxDepth) p.fail("nesting deeper than 256 levels");
+        }
+        ~Nest() { --p.depth_; }
+    };
     [[noreturn]] void fail(const char* what) const {
         throw std::runtime_error(std::string("JSON parse error at byte ") + std::to_string(p_) + ": " + what);
     }
@@ -81,6 +106,7 @@ class JsonParser {
         if (!std::strncmp(s_.c_str() + p_, "true", 4)) { p_ += 4; Json j; j.kind = Json::Bool; j.b = true; return j; }
         if (!std::strncmp(s_.c_str() + p_, "false", 5)) { p_ += 5; Json j; j.kind = Json::Bool; return j; }
         if (!std::strncmp(s_.c_str() + p_, "null", 4)) { p_ += 4; return Json{}; }
+        if (!(c == '-' || (c >= '0' && c <= '9'))) fail("bad value"); // strtod alone would take "nan", "inf", "0x10", "+1"
         char* end = nullptr;
         double v = std::strtod(s_.c_str() + p_, &end);
         if (end == s_.c_str() + p_) fail("bad value");
@@ -124,6 +150,7 @@ class JsonParser {
         return out;
     }
     Json array() {
+        Nest nest(*this);
         Json j;
         j.kind = Json::Array;
         ++p_;
@@ -138,6 +165,7 @@ class JsonParser {
         }
     }
     Json object() {
+        Nest nest(*this);
         Json j;
         j.kind = Json::Object;
         ++p_;

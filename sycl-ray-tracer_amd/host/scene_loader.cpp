@@ -142,12 +142,18 @@ View accessor(const Glb& g, int index) {
     View v;
     v.comp = acc.int_or("componentType", 0);
     v.ncomp = type_count(acc.at("type").str);
-    v.count = (size_t)acc.number_or("count", 0);
-    const size_t start = (size_t)bv.number_or("byteOffset", 0) + (size_t)acc.number_or("byteOffset", 0);
+    // every number is validated against the BIN chunk's size BEFORE it is cast, and the range check is written without
+    // sums or products that could wrap around in size_t (count = 2^61 with stride 8 used to pass)
+    const size_t size = g.bin.size();
+    v.count = acc.size_or("count", 0, size);
+    const size_t off_bv = bv.size_or("byteOffset", 0, size), off_acc = acc.size_or("byteOffset", 0, size);
     const size_t elem = comp_size(v.comp) * (size_t)v.ncomp;
-    const size_t bs = (size_t)bv.number_or("byteStride", 0);
+    const size_t bs = bv.size_or("byteStride", 0, size);
     v.stride = bs ? bs : elem;
-    if (v.count && start + (v.count - 1) * v.stride + elem > g.bin.size()) throw std::runtime_error("glTF: accessor out of bounds");
+    if (off_bv > size - off_acc) throw std::runtime_error("glTF: accessor out of bounds");
+    const size_t start = off_bv + off_acc;
+    if (v.count && !(elem <= size && start <= size - elem && (v.count - 1) <= (size - start - elem) / v.stride))
+        throw std::runtime_error("glTF: accessor out of bounds");
     v.base = g.bin.data() + start;
     return v;
 }
@@ -199,8 +205,8 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
         const Json& im = images.at(i);
         if (!im.has("bufferView")) throw std::runtime_error("glTF: image " + std::to_string(i) + " is not embedded in the GLB");
         const Json& bv = js.at("bufferViews").at((size_t)im.int_or("bufferView", 0));
-        const size_t off = (size_t)bv.number_or("byteOffset", 0), len = (size_t)bv.number_or("byteLength", 0);
-        if (off + len > g.bin.size()) throw std::runtime_error("glTF: image buffer view out of bounds");
+        const size_t off = bv.size_or("byteOffset", 0, g.bin.size()), len = bv.size_or("byteLength", 0, g.bin.size());
+        if (!(len <= g.bin.size() && off <= g.bin.size() - len)) throw std::runtime_error("glTF: image buffer view out of bounds");
         uint32_t w = 0, h = 0;
         std::vector<uint8_t> rgba;
         decode_image_rgba8(g.bin.data() + off, len, w, h, rgba);
@@ -245,7 +251,7 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
             m.ior = (float)ext.at("KHR_materials_ior").number_or("ior", 1.5);
             if (verbose) std::printf("Dielectric: ior=%g\n", m.ior);
         } else {
-            m.type = (float)metallic > 0.01f ? RT_MAT_METALLIC : RT_MAT_DIFFUSE;
+            m.type = metallic > (double)0.01f ? RT_MAT_METALLIC : RT_MAT_DIFFUSE; // double vs float-literal compare, as src/scene.cpp:219
             m.tex_kind = has_tex ? RT_TEX_IMAGE : RT_TEX_COLOR;
             m.tex_layer = has_tex ? tex_layer : 0u;
             for (int k = 0; k < 3; ++k) m.color[k] = (float)base[k], m.emissive[k] = (float)ef[k] * (float)strength;
@@ -339,11 +345,11 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
         const M4 global = mul(parent, local);
         if (n.has("camera")) cam_node = (int)ni, cam_global = global;
         if (n.has("children"))
-            for (size_t c = 0; c < n.at("children").size(); ++c) visit((size_t)n.at("children").at(c).num, global, depth + 1);
+            for (size_t c = 0; c < n.at("children").size(); ++c) visit(n.at("children").at(c).index_value(nodes.size()), global, depth + 1);
         if (n.has("mesh")) placed.push_back({ni, n.int_or("mesh", 0), global});
     };
     if (scene.has("nodes"))
-        for (size_t r = 0; r < scene.at("nodes").size(); ++r) visit((size_t)scene.at("nodes").at(r).num, identity(), 0);
+        for (size_t r = 0; r < scene.at("nodes").size(); ++r) visit(scene.at("nodes").at(r).index_value(nodes.size()), identity(), 0);
     // instances attach in NODE INDEX order (src/scene.cpp:101-106), primitives in order
     std::stable_sort(placed.begin(), placed.end(), [](const Placed& a, const Placed& b) { return a.node < b.node; });
     for (const Placed& pl : placed) {

@@ -376,22 +376,41 @@ def test_full_size_properties(gpu_scenes, oracle, scene_cache, cls, kind):
         assert nbad == 0, f"strip {strip}: {nbad} pixels differ from the oracle (rmse {rmse:.3e})"
 
 
-# BASELINE.json configs at their FULL sizes (config 5 at 8 of its 256 spp): the oracle cannot finish these in
-# seconds, so they are checked through size-independent properties; bit-parity at reduced sizes is above.
+def _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, got_f32, got_u8, strips, local_strip_of=lambda k: k, what=""):
+    """Bit-exact comparison of 8-row strips of a full-size GPU frame with the oracle. The oracle renders strip k alone as tile
+    (rank k, world n_strips) of the same frame at the SAME spp and depth (a pixel's RNG stream runs through all its samples,
+    so nothing can be reduced on one side only). `local_strip_of` maps a global strip index to its position in `got`."""
+    osc = oracle.OracleScene(sd)
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    n_strips = (h + 7) // 8
+    for k in strips:
+        f, b, _ = osc.render(ocam, kind, depth, spp, use_bvh=True, rank=k, world=n_strips, strip_rows=8)
+        lk = local_strip_of(k)
+        gf, gb = got_f32[lk * 8: lk * 8 + f.shape[0]], got_u8[lk * 8: lk * 8 + f.shape[0]]
+        nbad = int((gf != f).any(-1).sum())
+        rmse = float(np.sqrt(np.mean((gf.astype(np.float64) - f) ** 2)))
+        assert nbad == 0, f"{what} strip {k}: {nbad} pixels differ from the oracle (rmse {rmse:.3e}, tolerance {RMSE_TOL})"
+        np.testing.assert_array_equal(gb, b)
+
+
+# BASELINE.json configs 1-4 at their FULL sizes, both renderers where the config names both: size-independent properties
+# (ray bounds, clamping, unorm8 == quantised fp32, idempotence, tile split) PLUS a bit-exact oracle comparison of the listed
+# 8-row strips at the full spp and depth. Config 5 has its own test below.
 FULL_CONFIGS = [
-    ("triangle", {}, 256, 256, 1, 10, MegakernelRenderer),      # config 1
-    ("cube", {}, 512, 512, 16, 10, WavefrontRenderer),          # config 2
-    ("cornell", {}, 1024, 1024, 64, 10, WavefrontRenderer),     # config 3
-    ("cornell", {}, 1024, 1024, 64, 10, MegakernelRenderer),    # config 3, other renderer
-    ("atrium", {"detail": 4}, 1920, 1080, 64, 10, WavefrontRenderer),   # config 4 (the bench workload)
-    ("atrium", {"detail": 4}, 3840, 2160, 8, 16, WavefrontRenderer),    # config 5 geometry / size / depth, 8 spp
+    ("triangle", {}, 256, 256, 1, 10, MegakernelRenderer, (0, 15, 31)),      # config 1
+    ("cube", {}, 512, 512, 16, 10, WavefrontRenderer, (0, 30, 63)),          # config 2
+    ("cornell", {}, 1024, 1024, 64, 10, WavefrontRenderer, (40, 100)),       # config 3
+    ("cornell", {}, 1024, 1024, 64, 10, MegakernelRenderer, (40, 100)),      # config 3, other renderer
+    ("atrium", {"detail": 4}, 1920, 1080, 64, 10, WavefrontRenderer, (7, 66, 134)),   # config 4 (the bench workload)
+    ("atrium", {"detail": 4}, 1920, 1080, 64, 10, MegakernelRenderer, (7, 66, 134)),  # config 4, the bench's headline renderer
 ]
 
 
-@pytest.mark.parametrize("name,kw,w,h,spp,depth,cls", FULL_CONFIGS)
-def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, name, kw, w, h, spp, depth, cls):
+@pytest.mark.parametrize("name,kw,w,h,spp,depth,cls,strips", FULL_CONFIGS)
+def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, oracle, name, kw, w, h, spp, depth, cls, strips):
     sd = scene_cache(name, **kw)
     gs = gpu_scenes(name, **kw)
+    kind = abi.RT_RENDERER_WAVEFRONT if cls is WavefrontRenderer else abi.RT_RENDERER_MEGAKERNEL
     r = cls(gs, (w, h), depth, spp)
     cam = Camera.for_scene(sd, (w, h))
     a = r.render_frame(cam)
@@ -414,6 +433,36 @@ def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, name, kw, w, h, 
     r.close()
     assert rays == a.rays
     np.testing.assert_array_equal(assemble_tiles(parts, h, 2, 8), a.rgba_f32)
+    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, a.rgba_f32, a.rgba_u8, strips, what=f"{name} {w}x{h} {spp}spp {cls.__name__}")
+
+
+@pytest.mark.parametrize("cls,kind", [(WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT), (MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL)])
+def test_config5_as_stated_tile_0_of_8(gpu_scenes, scene_cache, oracle, cls, kind):
+    """BASELINE.json config 5 exactly as stated — atrium (detail 4, 283k triangles), 3840x2160, 256 spp, depth 16, the
+    wavefront renderer with wave compaction (and the megakernel beside it), the tile ONE GPU of the 8-GPU split renders:
+    rank 0 of world 8, 8-row strips (34 strips, 272 rows, 1.04 M pixels, ~2.6 G rays). Properties of the whole tile plus
+    a bit-exact oracle comparison of two of its strips at the full 256 spp and depth 16 (nothing is reduced: ~70 M rays per
+    strip, some tens of seconds on the host cores)."""
+    sd = scene_cache("atrium", detail=4)
+    gs = gpu_scenes("atrium", detail=4)
+    w, h, spp, depth, world = 3840, 2160, 256, 16, 8
+    r = cls(gs, (w, h), depth, spp)
+    r.set_tile(0, world, 8)
+    rows = r.global_rows()
+    assert len(rows) == 272 and all((y // 8) % world == 0 for y in rows)
+    a = r.render_frame(Camera.for_scene(sd, (w, h)))
+    r.close()
+    n_px = len(rows) * w
+    assert a.rgba_f32.shape == (272, w, 4)
+    assert n_px * spp <= a.rays <= n_px * spp * depth
+    assert 4.0 < a.rays / (n_px * spp) < 16.0  # enclosed scene: long paths
+    assert np.isfinite(a.rgba_f32).all() and (a.rgba_f32[..., 3] == 1).all() and (a.rgba_f32[..., :3] >= 0).all()
+    if cls is WavefrontRenderer:
+        assert a.rgba_f32[..., :3].max() <= 1.0
+    np.testing.assert_array_equal(a.rgba_u8[..., :3], np.rint(np.clip(a.rgba_f32[..., :3], 0, 1) * 255).astype(np.uint8))
+    # global strips 64 and 200 belong to rank 0 (64 % 8 == 200 % 8 == 0) and are its local strips 8 and 25
+    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, a.rgba_f32, a.rgba_u8, (64, 200), local_strip_of=lambda k: k // world,
+                                    what=f"config 5 {cls.__name__}")
 
 
 def _soup_scene(rng, n_tris, scale=1.0, offset=(0, 0, 0), duplicates=0, degenerate=0, n_inst=3):

@@ -122,6 +122,96 @@ def test_loader_error_paths(hostlib, tmp_path):
     assert hostlib.rth_load_glb(str(trunc).encode(), C.byref(h)) != 0
 
 
+def _craft_glb(path, js, bin_chunk=b""):
+    import json
+    import struct
+    j = json.dumps(js).encode() if not isinstance(js, bytes) else js
+    j += b" " * (-len(j) % 4)
+    b = bin_chunk + b"\0" * (-len(bin_chunk) % 4)
+    body = struct.pack("<II", len(j), 0x4E4F534A) + j + (struct.pack("<II", len(b), 0x004E4942) + b if b else b"")
+    path.write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + len(body)) + body)
+
+
+def test_loader_rejects_numbers_that_would_wrap_the_bounds_checks(hostlib, tmp_path):
+    """count / byteOffset / byteStride / byteLength come from JSON doubles. Values whose products wrap
+    around in size_t (count = 2^61 with stride 8), negative or non-finite values, and an image view whose offset + length
+    wraps must all be refused with an error, never read out of bounds; a deeply nested document must not overflow the stack."""
+    import struct
+    tri = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0)
+    nrm = struct.pack("<9f", 0, 0, 1, 0, 0, 1, 0, 0, 1)
+    uv = struct.pack("<6f", 0, 0, 1, 0, 0, 1)
+    idx = struct.pack("<3H", 0, 1, 2) + b"\0\0"
+    blob = tri + nrm + uv + idx
+
+    def doc(**over):
+        views = [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 36},
+                 {"buffer": 0, "byteOffset": 72, "byteLength": 24}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}]
+        accs = [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+                {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC2"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}]
+        d = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob)}], "bufferViews": views, "accessors": accs,
+             "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3}]}],
+             "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+        for k, v in over.items():
+            a, i, f = k.split("__")
+            d[a][int(i)][f] = v
+        return d
+
+    h = C.c_void_p()
+    good = tmp_path / "good.glb"
+    _craft_glb(good, doc(), blob)
+    assert hostlib.rth_load_glb(str(good).encode(), C.byref(h)) == 0, hostlib.rth_last_error()
+    hostlib.rth_scene_free(h)
+    bad_cases = {
+        "count_2p61_stride8": doc(accessors__0__count=2 ** 61, bufferViews__0__byteStride=8),  # (count-1)*stride wraps to a small number
+        "count_huge": doc(accessors__3__count=1e300),
+        "count_negative": doc(accessors__0__count=-3),
+        "offset_negative": doc(bufferViews__1__byteOffset=-36),
+        "offset_2p64": doc(accessors__2__byteOffset=2.0 ** 64),
+        "stride_huge": doc(bufferViews__0__byteStride=2 ** 63),
+        "index_of_node_negative": {**doc(), "scenes": [{"nodes": [-1]}]},
+        "index_of_node_huge": {**doc(), "scenes": [{"nodes": [1e30]}]},
+    }
+    for name, d in bad_cases.items():
+        pth = tmp_path / f"{name}.glb"
+        _craft_glb(pth, d, blob)
+        assert hostlib.rth_load_glb(str(pth).encode(), C.byref(h)) != 0, name
+        assert hostlib.rth_last_error(), name
+    # image buffer view whose offset + length wraps around
+    d = doc()
+    d["images"] = [{"bufferView": 4, "mimeType": "image/png"}]
+    d["bufferViews"].append({"buffer": 0, "byteOffset": 8, "byteLength": 2.0 ** 64 - 4})
+    _craft_glb(tmp_path / "img_wrap.glb", d, blob)
+    assert hostlib.rth_load_glb(str(tmp_path / "img_wrap.glb").encode(), C.byref(h)) != 0
+    # NaN is not valid JSON; strtod would accept it: must be an error, not a cast of NaN
+    raw = b'{"asset":{"version":"2.0"},"accessors":[{"count":nan}],"scenes":[{"nodes":[]}]}'
+    _craft_glb(tmp_path / "nan.glb", raw, blob)
+    assert hostlib.rth_load_glb(str(tmp_path / "nan.glb").encode(), C.byref(h)) != 0
+    # 100k nested arrays: a parse error (depth limit), not a stack overflow
+    _craft_glb(tmp_path / "deep.glb", b"[" * 100000 + b"]" * 100000, b"")
+    assert hostlib.rth_load_glb(str(tmp_path / "deep.glb").encode(), C.byref(h)) != 0
+    assert b"nesting" in hostlib.rth_last_error()
+
+
+def test_metallic_threshold_is_compared_in_double_like_the_reference(hostlib, tmp_path):
+    """src/scene.cpp:219 compares the double metallicFactor with 0.01f promoted to double (0.00999999977648...): a factor
+    of exactly 0.01 is therefore METALLIC upstream. 0.0099999997 (below the float literal) stays diffuse."""
+    import struct
+    blob = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<9f", 0, 0, 1, 0, 0, 1, 0, 0, 1) + struct.pack("<6f", 0, 0, 1, 0, 0, 1) + struct.pack("<3H", 0, 1, 2) + b"\0\0"
+    for factor, exp in ((0.01, abi.RT_MAT_METALLIC), (0.0099999997, abi.RT_MAT_DIFFUSE), (0.0, abi.RT_MAT_DIFFUSE), (1.0, abi.RT_MAT_METALLIC)):
+        d = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob)}],
+             "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 36},
+                             {"buffer": 0, "byteOffset": 72, "byteLength": 24}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+             "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+                           {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC2"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+             "materials": [{"pbrMetallicRoughness": {"metallicFactor": factor}}],
+             "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]}],
+             "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+        pth = tmp_path / f"m_{factor}.glb"
+        _craft_glb(pth, d, blob)
+        cs = CppScene(hostlib, pth)
+        assert cs.materials[0].type == exp, factor
+
+
 def test_png_codec_against_pil(hostlib, tmp_path):
     from PIL import Image
     rng = np.random.default_rng(2)
