@@ -140,6 +140,7 @@ __device__ __forceinline__ float grid_step_dev(uint32_t biased_exp) { return __u
 // quantises the padded boxes of the nk children of one node (same rules as the host's quantise_node)
 __device__ void quantise_node_dev(BvhNode& n, int nk, const Box3* kb, float pad) {
     float nlo[3];
+    n.scale_x = n.scale_y = n.scale_z = 1.0f;
     for (int a = 0; a < 3; ++a) {
         float lo = kb[0].lo[a] - pad, hi = kb[0].hi[a] + pad;
         for (int k = 1; k < nk; ++k) lo = fminf(lo, kb[k].lo[a] - pad), hi = fmaxf(hi, kb[k].hi[a] + pad);
@@ -168,14 +169,14 @@ __device__ void quantise_node_dev(BvhNode& n, int nk, const Box3* kb, float pad)
             }
             if (ok) {
                 n.q[2 * a] = lo_b, n.q[2 * a + 1] = hi_b;
-                if (a == 0) n.exps = 0;
-                n.exps |= (uint32_t)(e + 127) << (8 * a);
+                if (a == 0) n.scale_x = s;
+                else if (a == 1) n.scale_y = s;
+                else n.scale_z = s;
                 break;
             }
             if (e > 120) break;
         }
     }
-    n.pad[0] = n.pad[1] = 0;
 }
 
 // frontier entry: binary internal node -> BVH4 node slot

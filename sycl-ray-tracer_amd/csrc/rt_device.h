@@ -211,8 +211,8 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) {
 }
 
 // The first kTopNodes nodes of the breadth-first node array (the top ~5 levels of the BVH4) are staged in
-// LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes so that the 16-byte
-// reads of different nodes spread over the banks. Measured on the atrium: 9.5 of the 17.9 inner-node
+// LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes of 16 bytes per node (the node's
+// four 16-byte words), so that the 16-byte reads of different nodes spread over the banks. Measured on the atrium: 9.5 of the 17.9 inner-node
 // visits of an average ray fall into these nodes; taking them out of the vector L1 path (the first
 // versions were bound by L1 tag throughput: ~1 lane-load per cycle and CU) is worth more than any ALU saving.
 #ifndef RT_TOP_NODES
@@ -222,25 +222,41 @@ constexpr int kTopNodes = RT_TOP_NODES;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 struct TopTree {
-    lds_u32x4* w0; // origin.xyz, exps
+    lds_u32x4* w0; // origin.xyz, scale.x
     lds_u32x4* w1; // qlo_x, qhi_x, qlo_y, qhi_y
-    lds_u32x2* w2; // qlo_z, qhi_z
+    lds_u32x4* w2; // qlo_z, qhi_z, scale.y, scale.z
     lds_u32x4* ch; // child[4]
     int32_t count; // nodes staged (0 = none)
 };
 // cooperative fill by the whole workgroup; the caller synchronises afterwards
-RT_DEV void top_tree_fill(const SceneDev& S, u32x4* w0, u32x4* w1, u32x2* w2, u32x4* ch, int32_t count) {
+RT_DEV void top_tree_fill(const SceneDev& S, u32x4* w0, u32x4* w1, u32x4* w2, u32x4* ch, int32_t count) {
     for (int32_t i = (int32_t)threadIdx.x; i < count; i += (int32_t)blockDim.x) {
         const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + i);
         w0[i] = np[0];
         w1[i] = np[1];
-        const u32x4 t = np[2];
-        w2[i] = u32x2{t.x, t.y};
+        w2[i] = np[2];
         ch[i] = np[3];
     }
 }
+
+// ---- instruction selection helpers (profiles/r02_valu_calibration.json) ------------------------------------------------
+// The traversal kernels are bound by VALU issue cycles, and on gfx950 a select is cheap or dear by its ENCODING: v_cndmask_b32_e64
+// on an SGPR pair costs 4 cycles, the VOP2 form on VCC 16 unless it directly follows the compare that wrote VCC. hipcc picks either;
+// these helpers pin the compare to an SGPR-pair result (ballot) and the select to the e64 form.
+typedef unsigned long long lmask;
+RT_DEV lmask lanes(bool c) { return __builtin_amdgcn_ballot_w64(c); } // v_cmp_*_e64 into an SGPR pair
+RT_DEV float sel(lmask m, float a, float b) { // m ? b : a
+    float d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m));
+    return d;
+}
+RT_DEV uint32_t sel(lmask m, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m));
+    return d;
+}
+RT_DEV int32_t sel(lmask m, int32_t a, int32_t b) { return (int32_t)sel(m, (uint32_t)a, (uint32_t)b); }
 
 // byte k of a word as float (v_cvt_f32_ubyteK)
 RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
@@ -253,32 +269,34 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 //   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
 // The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
 // min/max pairing is needed.
+// VALU budget of one step (cycles per wave, from the calibrated costs: fma/mul 2, everything else 4): 3 mul + 3 fma 12, sign selects
+// 3 cmp + 6 sel 36, per child 6 cvt + 6 fma + max/max3 + min/min3 + cmp + sel 60 (x4 = 240), sort RT_SORT_CE x (cmp + 4 sel) 20 each,
+// pushes / pop ~60: ~420 with the 5-comparator network, ~380 with the 3-comparator one.
+#ifndef RT_SORT_CE
+#define RT_SORT_CE 5 // 5: full sorting network. 3: nearest child exact, the (at most three) pushed ones in network order only
+#endif
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top) {
-    u32x4 w0, w1, chw;
-    u32x2 w2;
+    u32x4 w0, w1, w2, chw;
     if (T.cur < top.count) { // top of the tree: LDS
         w0 = top.w0[T.cur], w1 = top.w1[T.cur], w2 = top.w2[T.cur], chw = top.ch[T.cur];
     } else {
         const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + T.cur);
-        w0 = np[0], w1 = np[1];
-        w2 = *reinterpret_cast<const u32x2*>(np + 2);
-        chw = np[3];
+        w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
     }
-    const int4 ch = make_int4((int)chw.x, (int)chw.y, (int)chw.z, (int)chw.w);
-    const float ax = __uint_as_float((w0.w & 0xffu) << 23) * T.ix;
-    const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * T.iy;
-    const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * T.iz;
+    const float ax = __uint_as_float(w0.w) * T.ix;
+    const float ay = __uint_as_float(w2.z) * T.iy;
+    const float az = __uint_as_float(w2.w) * T.iz;
     const float bx = __builtin_fmaf(__uint_as_float(w0.x), T.ix, T.ox);
     const float by = __builtin_fmaf(__uint_as_float(w0.y), T.iy, T.oy);
     const float bz = __builtin_fmaf(__uint_as_float(w0.z), T.iz, T.oz);
-    const bool nx = T.ix < 0.0f, ny = T.iy < 0.0f, nz = T.iz < 0.0f;
-    const uint32_t qnx = nx ? w1.y : w1.x, qfx = nx ? w1.x : w1.y;
-    const uint32_t qny = ny ? w1.w : w1.z, qfy = ny ? w1.z : w1.w;
-    const uint32_t qnz = nz ? w2.y : w2.x, qfz = nz ? w2.x : w2.y;
+    const lmask nx = lanes(T.ix < 0.0f), ny = lanes(T.iy < 0.0f), nz = lanes(T.iz < 0.0f);
+    const uint32_t qnx = sel(nx, w1.x, w1.y), qfx = sel(nx, w1.y, w1.x);
+    const uint32_t qny = sel(ny, w1.z, w1.w), qfy = sel(ny, w1.w, w1.z);
+    const uint32_t qnz = sel(nz, w2.x, w2.y), qfz = sel(nz, w2.y, w2.x);
     const float inf = __builtin_huge_valf();
     // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
-    // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 was
-    // measured 3 % slower than scalar v_fma_f32 here.)
+    // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 costs
+    // 4 cycles per pair, the same as two v_fma_f32.)
     float k0, k1, k2, k3;
 #define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
@@ -286,40 +304,45 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
                                          __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
-        K = tn <= tf ? tn : inf;                                                                         \
+        K = sel(lanes(tn <= tf), inf, tn);                                                               \
     }
     RT_CHILD(k0, ub0)
     RT_CHILD(k1, ub1)
     RT_CHILD(k2, ub2)
     RT_CHILD(k3, ub3)
 #undef RT_CHILD
-    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-    // 5-comparator sorting network on (entry distance, child); misses carry +inf and sink to the end
-#define RT_CE(KA, CA, KB, CB)                                   \
-    {                                                          \
-        const bool sw = KB < KA;                               \
-        const float ka = sw ? KB : KA, kb = sw ? KA : KB;      \
-        const int32_t ca = sw ? CB : CA, cb = sw ? CA : CB;    \
-        KA = ka, KB = kb, CA = ca, CB = cb;                    \
+    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
+    // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
+    // SGPR pair + four e64 selects on it (18 cycles).
+#define RT_CE(KA, CA, KB, CB)                                                        \
+    {                                                                               \
+        const lmask sw = lanes(KB < KA);                                            \
+        const float ka = sel(sw, KA, KB), kb = sel(sw, KB, KA);                     \
+        const int32_t ca = sel(sw, CA, CB), cb = sel(sw, CB, CA);                   \
+        KA = ka, KB = kb, CA = ca, CB = cb;                                         \
     }
     RT_CE(k0, c0, k1, c1)
     RT_CE(k2, c2, k3, c3)
     RT_CE(k0, c0, k2, c2)
+#if RT_SORT_CE >= 5
     RT_CE(k1, c1, k3, c3)
     RT_CE(k1, c1, k2, c2)
+#else
+    // after three comparators k0 is the minimum; hits are no longer a prefix of (k1, k2, k3), each is tested on its own below
+#endif
 #undef RT_CE
-    if (k3 < inf) stk_push(stack, T, c3); // farthest first
+    if (k3 < inf) stk_push(stack, T, c3); // farthest first (exactly so with the full network)
     if (k2 < inf) stk_push(stack, T, c2);
     if (k1 < inf) stk_push(stack, T, c1);
     if (k0 < inf) T.cur = c0;
     else trav_pop(T, stack);
 }
 
-// leaf step. BATCH = false: ONE triangle of the leaf per step, then the next one or pop (EXTEND: 64 VGPRs leave no
-// room for more). BATCH = true: all 1..4 triangles in this step — a lane at a leaf waits for the leaf class to win
+// leaf step. BATCH = false: ONE triangle of the leaf per step, then the next one or pop (rt_intersect_batch).
+// BATCH = true (both renderers): all 1..4 triangles in this step — a lane at a leaf waits for the leaf class to win
 // the wave's vote, so every extra leaf step costs it several iterations; the next record is fetched while the current
 // one is tested (two in flight, 24 VGPRs), the loop bound is the wave's largest leaf (uniform branch). Measured on the
-// megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; on EXTEND the extra registers spill: -25 %.
+// megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
 template <bool BATCH>
 RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;

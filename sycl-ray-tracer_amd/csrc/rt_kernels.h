@@ -43,14 +43,13 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
 
 // LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
-    __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_ch[kTopNodes];                          \
-    __shared__ u32x2 top_w2[kTopNodes];                                                                \
+    __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_w2[kTopNodes], top_ch[kTopNodes];       \
     __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
     int32_t spill[kStackSize - kLdsStack];                                                             \
     const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
     top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
     __syncthreads();                                                                                   \
-    const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x2*)top_w2, (lds_u32x4*)top_ch, top_count}; \
+    const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
     const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, (BLOCK)};
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
@@ -108,12 +107,21 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #ifndef RT_MEGA_TAIL_SHADE_PCT
 #define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
 #endif
+#ifndef RT_MEGA_TAIL_UNROLL1
+#define RT_MEGA_TAIL_UNROLL1 0
+#endif
 #ifndef RT_MEGA_PRIO
 #define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
                        // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
 #endif
 #ifndef RT_MEGA_UNROLL
 #define RT_MEGA_UNROLL 3 // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
+#endif
+#ifndef RT_MEGA_GSS
+#define RT_MEGA_GSS 0 // guided self-scheduling of the pixel queue (see the refill step): measured, off
+#endif
+#ifndef RT_MEGA_GSS_MIN
+#define RT_MEGA_GSS_MIN 1u // live lanes a wave may always hold
 #endif
 #ifndef RT_MEGA_BLOCK
 #define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
@@ -148,6 +156,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     const uint32_t region_slots = ((n_slots + 7u) / 8u + 63u) & ~63u;
     uint32_t region = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID[3:0]
     uint32_t regions_done = 0;
+    const uint32_t region_left = region_slots;                                                  // slots of one region
+    const uint32_t waves_per_region = (gridDim.x * (RT_MEGA_BLOCK / 64u) + 7u) / 8u;           // the waves that start on it
+    uint32_t last_base = 0; // cursor of the current region as this wave last saw it
+    (void)region_left, (void)waves_per_region, (void)last_base; // only read with RT_MEGA_GSS
     for (;;) {
         // REFILL: idle lanes take the next pixels from the frame-wide cursor, one atomic per wave and round.
         // A wave is persistent: it keeps pulling pixels until the frame is exhausted, so a lane whose
@@ -155,17 +167,35 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         if (!exhausted) {
             const unsigned long long idle_m = __ballot(!live);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            if (cnt >= RT_MEGA_REFILL) {
+            // RT_MEGA_GSS=1 (experiment, OFF): guided self-scheduling of the pixel queue — a wave may hold at most remaining pixels /
+            // waves live lanes, so that the last pixels of the queue (and all pixels of a small tile) are spread thinly over ALL
+            // waves instead of filling a few of them. The idea was that a pixel's chain runs faster in a wave with few live lanes.
+            // It does not: a lane whose traversal is complete still waits for RT_MEGA_SHADE_PCT of its wave, so the chain is paced
+            // by the slowest lanes whatever their number. Measured (64 spp, 1080p atrium): full frame 153 -> 210 ms (the last fifth
+            // of every region runs in under-filled waves), 1/8 tile 34.1 -> 32.1 ms, 1/16 tile 28.6 -> 29.0 ms. Scheduling only:
+            // every pixel is computed exactly as before.
+            uint32_t take = cnt;
+#if RT_MEGA_GSS
+            {
+                const uint32_t remaining = region_left > last_base ? region_left - last_base : 0u; // as of this wave's last fetch
+                const uint32_t quota = remaining / waves_per_region + RT_MEGA_GSS_MIN;
+                const uint32_t n_now = 64u - cnt;
+                take = quota > n_now ? (quota - n_now < cnt ? quota - n_now : cnt) : 0u;
+            }
+#endif
+            if (cnt >= RT_MEGA_REFILL && take) {
                 // The frame's pixel slots are cut into 8 contiguous regions, one per XCD: a wave first drains the
                 // region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others. Waves that share an
                 // L2 thus work on one part of the picture, i.e. on the same part of the scene (speed only: any
                 // placement gives the same image).
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(pixel_cursor + region, cnt);
+                if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const uint32_t rel = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                last_base = base + take;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const uint32_t rel = base + rank;
                 const uint32_t p = region * region_slots + rel;
-                if (!live && rel < region_slots && p < n_slots) {
+                if (!live && rank < take && rel < region_slots && p < n_slots) {
                     const uint32_t t = p >> 6;
                     x = (int)((t % tiles_x) * 8u + (p & 7u));
                     ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
@@ -179,8 +209,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                         live = true;
                     }
                 }
-                if (base + cnt >= region_slots) { // this region is used up: move on to the next one
+                if (base + take >= region_slots) { // this region is used up: move on to the next one
                     region = (region + 1u) & 7u;
+                    last_base = 0;
                     exhausted = ++regions_done >= 8u;
                     if (STATS && exhausted) wall_exhausted = wall_clock64();
                 }
@@ -198,6 +229,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
             if (STATS) ws.live_lane_steps += n_live;
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+#if RT_MEGA_TAIL_UNROLL1
+            if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
+#endif
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) { // the exit tests are checked every RT_MEGA_UNROLL steps
                 if (STATS) ws.live_lane_steps += n_live;
@@ -337,6 +371,10 @@ constexpr uint32_t kExtendRefill = RT_EXTEND_REFILL;
 #ifndef RT_EXTEND_BLOCK
 #define RT_EXTEND_BLOCK 1024
 #endif
+#ifndef RT_EXTEND_LEAF_BATCH
+#define RT_EXTEND_LEAF_BATCH true // whole-leaf steps as in the megakernel (~24 more VGPRs than one triangle per step: they fit in EXTEND's 64
+                                  // since SLP packing is off; round 1: spills, -25 %; now +6 % on the wavefront frame)
+#endif
 template <bool STATS>
 __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(SceneDev S, QueueDev qin, float4* __restrict__ hits,
                                                                     const uint32_t* __restrict__ count_in,
@@ -413,11 +451,11 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
             continue;
         }
         if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-        (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
+        (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, &ws);
 #pragma unroll
         for (int k = 1; k < RT_EXTEND_UNROLL; ++k) { // refill is looked at every RT_EXTEND_UNROLL steps
             if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-            (void)trav_step_wave<STATS>(S, T, stack, top, &ws);
+            (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, &ws);
         }
     }
     if (STATS && lane == 0) {

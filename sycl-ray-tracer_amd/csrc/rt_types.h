@@ -7,22 +7,26 @@ namespace rt {
 
 // ---- BVH ----------------------------------------------------------------------------------------
 // 4-wide BVH, 64-byte nodes, child boxes quantised to 8 bits per plane on a per-node grid:
-//     plane = origin[axis] + q * 2^(exp[axis] - 127)          (q = 0..255)
+//     plane = origin[axis] + q * scale[axis]                  (q = 0..255, scale a power of two)
 // quantised conservatively (lo rounded down, hi rounded up) after padding, so a decoded box always
 // contains the padded exact box. One node = 4 x dwordx4 loads and decides FOUR children (the first
 // version, a BVH2 with fp32 boxes, needed the same 4 loads for two): half the L1 accesses per box
 // and half the dependent fetches per ray.
-//   word 0-2  origin.xyz (f32)      word 3     ex | ey << 8 | ez << 16 (biased f32 exponents)
+//   word 0-2  origin.xyz (f32)      word 3     scale.x (f32, a power of two: the grid step of the x planes)
 //   word 4-9  qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z : byte k belongs to child k
-//   word 10-11 unused               word 12-15 child[4]
+//   word 10-11 scale.y, scale.z     word 12-15 child[4]
+// (Round 1 packed the three biased exponents into word 3; rebuilding the floats cost 3 x (v_lshlrev 4 + v_and 2 cycles) per
+//  node visit on a VALU-bound kernel — profiles/r02_valu_calibration.json — and the two spare words were there.)
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 2) | (count - 1), with
 // `first` indexing the leaf-ordered triangle array and 1 <= count <= 4.  child == kChildEmpty: absent.
 struct alignas(64) BvhNode {
     float origin[3];
-    uint32_t exps;
+    float scale_x;
     uint32_t q[6]; // qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z
-    uint32_t pad[2];
+    float scale_y, scale_z;
     int32_t child[4];
+    float scale(int a) const { return a == 0 ? scale_x : (a == 1 ? scale_y : scale_z); }
+    void set_scale(int a, float s) { (a == 0 ? scale_x : (a == 1 ? scale_y : scale_z)) = s; }
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 constexpr int32_t kChildEmpty = (int32_t)0x80000000;

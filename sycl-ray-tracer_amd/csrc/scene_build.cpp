@@ -369,7 +369,6 @@ bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)
         n.origin[a] = nlo[a];
     }
     uint32_t q[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t exps = 0;
     for (int a = 0; a < 3; ++a) {
         const double ext = (double)nhi[a] - (double)nlo[a];
         int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
@@ -394,15 +393,13 @@ bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)
             }
             if (ok) {
                 q[2 * a] = lo_b, q[2 * a + 1] = hi_b;
-                exps |= (uint32_t)(e + 127) << (8 * a);
+                n.set_scale(a, s);
                 break;
             }
             if (e > 120) return false;
         }
     }
-    n.exps = exps;
     for (int i = 0; i < 6; ++i) n.q[i] = q[i];
-    n.pad[0] = n.pad[1] = 0;
     return true;
 }
 
@@ -495,7 +492,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
 
     auto empty_node = []() {
         BvhNode n{};
-        n.exps = (127u) | (127u << 8) | (127u << 16);
+        n.scale_x = n.scale_y = n.scale_z = 1.0f;
         for (int i = 0; i < 6; ++i) n.q[i] = (i & 1) ? 0u : 0xFFFFFFFFu; // qlo = 255, qhi = 0
         for (int k = 0; k < 4; ++k) n.child[k] = kChildEmpty;
         return n;
@@ -731,7 +728,7 @@ int check_bvh(const HostScene& hs, std::string& err) {
                 B c = walk(n.child[k], depth + 1);
                 if (!ok) return r;
                 for (int a = 0; a < 3; ++a) {
-                    const float s = grid_step((n.exps >> (8 * a)) & 0xffu);
+                    const float s = n.scale(a);
                     const float dlo = n.origin[a] + (float)((n.q[2 * a] >> (8 * k)) & 0xffu) * s;
                     const float dhi = n.origin[a] + (float)((n.q[2 * a + 1] >> (8 * k)) & 0xffu) * s;
                     // the decoded box must contain the subtree with at least half the builder's pad to spare
