@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -173,7 +173,7 @@ int32_t rt_renderer_local_rows(const rt_renderer* r);
 /* Global row index of local row `local_row` (for de-interleaving a gathered frame). */
 int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row);
 
-/* Per-launch hipEvent timing of the dominant kernel (k_wf_shoot; the megakernel is always timed).
+/* Per-launch hipEvent timing of the dominant kernel (k_wf_extend; the megakernel is always timed).
  * Off by default for the wavefront renderer (it adds two event records per bounce); also enabled
  * by the environment variable RT_PROFILE_KERNELS=1 at renderer creation. No reference counterpart
  * (the reference's print_elapsed helper is commented out: src/render_wavefront.cpp:129-137). */
@@ -216,6 +216,35 @@ int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f3
  * No reference counterpart (the reference blocks after every kernel: src/render_wavefront.cpp:396-431). */
 int rt_render_frame_begin(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream);
 int rt_render_frame_end(rt_renderer* r, rt_stats* stats);
+
+/* ---- Multi-GPU frame gather over xGMI (no reference counterpart: the reference renders on ONE device and hands its
+ * single image to stbi_write_png, src/main.cpp:57-70, src/util.hpp:8-33). SURVEY §8(e): the frame is split into interleaved
+ * strips (rt_renderer_set_tile), every GPU renders its strips into its own compact device buffer, and ONE collective brings
+ * them to the root GPU: ncclGather of the per-GPU strip buffers (rccl.h: ncclCommInitAll / ncclGroupStart / ncclGather /
+ * ncclGroupEnd) followed by a de-interleave kernel on the root. The frame touches host memory only when the caller asks
+ * for it (the PNG). librccl.so is loaded on first use (dlopen): single-GPU callers never load it.
+ *
+ * One process drives all devices (the C++ adapter's `--devices A,B,..`); the one-process-per-GPU form of the same gather is
+ * torch.distributed (backend nccl = RCCL) in rtamd/dist.py. */
+typedef struct rt_comm rt_comm;
+/* Communicator over `n` devices, rank i on devices[i]; rank 0 is the root. If the same device appears more than once
+ * (rehearsal of an n-GPU split on fewer GPUs) RCCL cannot be used (one rank per device): the gather then moves the strips
+ * with device-to-device copies and runs the same de-interleave kernel; rt_comm_uses_rccl() tells which. */
+int rt_comm_create(int n, const int* devices, rt_comm** out);
+void rt_comm_destroy(rt_comm* c);
+int rt_comm_uses_rccl(const rt_comm* c);
+/* The renderer's own device buffers of its tile (local_rows x W x 4 floats / bytes): render into them without any host copy
+ * with rt_render_frame_begin(r, cam, rt_renderer_tile_f32(r), rt_renderer_tile_u8(r), NULL) + rt_render_frame_end. */
+void* rt_renderer_tile_f32(rt_renderer* r);
+void* rt_renderer_tile_u8(rt_renderer* r);
+/* Gathers the last frame of renderers[0..n-1] — renderer i must be tile (i, n, strip_rows) of one W x H frame on devices[i],
+ * rendered into its own tile buffers — into the full frame on the root device and, if the pointers are not NULL, copies it
+ * to the host (rgba_f32: H*W*4 floats, rgba_u8: H*W*4 bytes; the f32 / u8 planes are only gathered when asked for here or
+ * through want_device_*). The device-resident frame stays valid until the next gather: rt_comm_frame_f32 / _u8. */
+int rt_frame_gather(rt_comm* c, rt_renderer* const* renderers, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32,
+                    int want_device_u8);
+const void* rt_comm_frame_f32(const rt_comm* c);
+const void* rt_comm_frame_u8(const rt_comm* c);
 
 /* ---- Device unit probes (parity tests of the building blocks; tiny launches) --------------- */
 /* XorShift32State::operator() (src/xorshift.hpp:11-20) run on the device: n draws from `seed`. */

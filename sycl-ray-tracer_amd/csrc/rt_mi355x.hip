@@ -5,6 +5,8 @@
 // here is ONE asynchronous stream of launches: queue lengths live in device memory, one counter
 // per (sample, depth), so no bounce ever waits for the host.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl.so is dlopen()ed by rt_comm_create
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -195,8 +197,14 @@ int alloc_tile_buffers(rt_renderer* r) {
     const size_t n = std::max<size_t>(r->n_local, 1);
     const char* ks = std::getenv("RT_KERNEL_STATS");
     if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void**)&r->d_f32, n * 16));
-    HIPCHK(hipMalloc((void**)&r->d_u8, n * 4));
+    // sized for the LONGEST tile of the split (rank 0's): ncclGather sends the same count from every rank
+    TileDev t0 = r->tile;
+    t0.rank = 0;
+    const size_t n_pad = std::max<size_t>((size_t)rows_of_tile(t0, r->height) * (size_t)r->width, n);
+    HIPCHK(hipMalloc((void**)&r->d_f32, n_pad * 16));
+    HIPCHK(hipMalloc((void**)&r->d_u8, n_pad * 4));
+    HIPCHK(hipMemset(r->d_f32, 0, n_pad * 16));
+    HIPCHK(hipMemset(r->d_u8, 0, n_pad * 4));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors
     } else {
@@ -769,6 +777,217 @@ int rt_render_frame_end(rt_renderer* r, rt_stats* stats) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
     return no_throw([&] { return frame_end(r, stats); });
 }
+
+} // extern "C"
+
+// ---- multi-GPU frame gather: ncclGather of the strip buffers + de-interleave on the root -------------------
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok() const { return lib && CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString; }
+};
+
+RcclApi& rccl() { // loaded once, on the first rt_comm_create that needs it
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (a.lib) {
+            a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.lib, "ncclCommInitAll");
+            a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+            a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
+            a.Gather = (decltype(a.Gather))dlsym(a.lib, "ncclGather");
+            a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        }
+        return a;
+    }();
+    return api;
+}
+
+#define NCCLCHK(expr)                                                                                     \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+
+// gathered[rank][row][x] (every rank padded to rows_max rows) -> full[global row][x]; one thread per pixel of the frame
+__global__ void __launch_bounds__(256) k_deinterleave(uint32_t width, uint32_t height, uint32_t world, uint32_t strip_rows, uint32_t rows_max,
+                                                       const float4* __restrict__ g_f32, const uint32_t* __restrict__ g_u8,
+                                                       float4* __restrict__ full_f32, uint32_t* __restrict__ full_u8) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t x = i % width, y = i / width;
+    const uint32_t strip = y / strip_rows, rank = strip % world;
+    const uint32_t local_row = (strip / world) * strip_rows + y % strip_rows; // the inverse of tile_global_row
+    const size_t src = ((size_t)rank * rows_max + local_row) * width + x;
+    if (g_f32) full_f32[i] = g_f32[src];
+    if (g_u8) full_u8[i] = g_u8[src];
+}
+
+} // namespace
+
+struct rt_comm {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms; // empty: local mode (a device appears more than once)
+    bool use_rccl = false;
+    // root-device buffers, (re)allocated when the frame geometry changes
+    int32_t width = 0, height = 0;
+    uint32_t rows_max = 0;
+    float4* d_gather_f32 = nullptr;
+    uint32_t* d_gather_u8 = nullptr;
+    float4* d_full_f32 = nullptr;
+    uint32_t* d_full_u8 = nullptr;
+    hipStream_t root_stream = nullptr;
+};
+
+namespace {
+void comm_free_buffers(rt_comm* c) {
+    auto fr = [](auto*& p) {
+        if (p) (void)hipFree((void*)p);
+        p = nullptr;
+    };
+    fr(c->d_gather_f32), fr(c->d_gather_u8), fr(c->d_full_f32), fr(c->d_full_u8);
+}
+} // namespace
+
+extern "C" {
+
+int rt_comm_create(int n, const int* devices, rt_comm** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    if (n <= 0 || n > 64 || !devices) return fail(RT_ERR_INVALID, "bad device list");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) {
+        if (devices[i] < 0 || devices[i] >= n_dev) return fail(RT_ERR_INVALID, "device index out of range");
+        for (int j = 0; j < i; ++j) distinct = distinct && devices[j] != devices[i];
+    }
+    return no_throw([&] {
+        rt_comm* c = new rt_comm();
+        c->devices.assign(devices, devices + n);
+        auto bail = [&](int code) {
+            rt_comm_destroy(c);
+            return code;
+        };
+        if (hipSetDevice(devices[0]) != hipSuccess || hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(RT_ERR_HIP, "cannot create a stream on the root device"));
+        if (distinct) { // one rank per device: RCCL over xGMI
+            if (!rccl().ok()) return bail(fail(RT_ERR_UNSUPPORTED, std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing")));
+            c->comms.assign((size_t)n, nullptr);
+            const ncclResult_t rc = rccl().CommInitAll(c->comms.data(), n, devices);
+            if (rc != ncclSuccess) {
+                c->comms.clear();
+                return bail(fail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(rc)));
+            }
+            c->use_rccl = true;
+        }
+        *out = c;
+        return (int)RT_OK;
+    });
+}
+
+void rt_comm_destroy(rt_comm* c) {
+    if (!c) return;
+    for (size_t i = 0; i < c->comms.size(); ++i)
+        if (c->comms[i] && hipSetDevice(c->devices[i]) == hipSuccess) (void)rccl().CommDestroy(c->comms[i]);
+    if (!c->devices.empty() && hipSetDevice(c->devices[0]) == hipSuccess) {
+        if (c->root_stream) (void)hipStreamSynchronize(c->root_stream);
+        comm_free_buffers(c);
+        if (c->root_stream) (void)hipStreamDestroy(c->root_stream);
+    }
+    delete c;
+}
+
+int rt_comm_uses_rccl(const rt_comm* c) { return c && c->use_rccl ? 1 : 0; }
+const void* rt_comm_frame_f32(const rt_comm* c) { return c ? c->d_full_f32 : nullptr; }
+const void* rt_comm_frame_u8(const rt_comm* c) { return c ? c->d_full_u8 : nullptr; }
+void* rt_renderer_tile_f32(rt_renderer* r) { return r ? r->d_f32 : nullptr; }
+void* rt_renderer_tile_u8(rt_renderer* r) { return r ? r->d_u8 : nullptr; }
+
+int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32, int want_device_u8) {
+    if (!c || !rs) return fail(RT_ERR_INVALID, "null communicator or renderer list");
+    const uint32_t n = (uint32_t)c->devices.size();
+    const bool f32 = rgba_f32 || want_device_f32, u8 = rgba_u8 || want_device_u8;
+    if (!f32 && !u8) return fail(RT_ERR_INVALID, "nothing to gather: ask for the f32 and / or the u8 plane");
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_renderer* r = rs[i];
+        if (!r) return fail(RT_ERR_INVALID, "null renderer");
+        if (r->frame_pending) return fail(RT_ERR_INVALID, "a renderer still has a frame in flight (rt_render_frame_end first)");
+        if (r->scene->device != c->devices[i]) return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " is not on the communicator's device " + std::to_string(c->devices[i]));
+        if (r->width != rs[0]->width || r->height != rs[0]->height) return fail(RT_ERR_INVALID, "renderers differ in frame size");
+        if (r->tile.world != n || r->tile.rank != i || r->tile.strip_rows != rs[0]->tile.strip_rows)
+            return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " is not tile (" + std::to_string(i) + ", " + std::to_string(n) + ") of the frame");
+    }
+    return no_throw([&]() -> int {
+        const int32_t W = rs[0]->width, H = rs[0]->height;
+        const uint32_t strip = rs[0]->tile.strip_rows, rows_max = (uint32_t)rs[0]->tile.local_rows; // rank 0 owns the most rows
+        const size_t tile_px = (size_t)rows_max * (size_t)W, frame_px = (size_t)W * (size_t)H;
+        HIPCHK(hipSetDevice(c->devices[0]));
+        if (c->width != W || c->height != H || c->rows_max != rows_max) {
+            HIPCHK(hipStreamSynchronize(c->root_stream));
+            comm_free_buffers(c);
+            c->width = W, c->height = H, c->rows_max = rows_max;
+        }
+        if (f32 && !c->d_full_f32) {
+            HIPCHK(hipMalloc((void**)&c->d_gather_f32, std::max<size_t>(1, tile_px * n) * 16));
+            HIPCHK(hipMalloc((void**)&c->d_full_f32, std::max<size_t>(1, frame_px) * 16));
+        }
+        if (u8 && !c->d_full_u8) {
+            HIPCHK(hipMalloc((void**)&c->d_gather_u8, std::max<size_t>(1, tile_px * n) * 4));
+            HIPCHK(hipMalloc((void**)&c->d_full_u8, std::max<size_t>(1, frame_px) * 4));
+        }
+        if (frame_px == 0) return RT_OK;
+        if (c->use_rccl) {
+            // ONE grouped collective per plane: every rank sends rows_max * W pixels from its own stream (ordered behind its
+            // render), the root receives n blocks. Single-process multi-device RCCL calls must be grouped (rccl.h:213).
+            NCCLCHK(rccl().GroupStart());
+            for (uint32_t i = 0; i < n; ++i) {
+                HIPCHK(hipSetDevice(c->devices[i]));
+                if (f32) NCCLCHK(rccl().Gather(rs[i]->d_f32, i == 0 ? (void*)c->d_gather_f32 : nullptr, tile_px * 4, ncclFloat, 0, c->comms[i], rs[i]->stream));
+                if (u8) NCCLCHK(rccl().Gather(rs[i]->d_u8, i == 0 ? (void*)c->d_gather_u8 : nullptr, tile_px * 4, ncclUint8, 0, c->comms[i], rs[i]->stream));
+            }
+            NCCLCHK(rccl().GroupEnd());
+            for (uint32_t i = 0; i < n; ++i) { // the root's stream receives; the others only have to have sent
+                HIPCHK(hipSetDevice(c->devices[i]));
+                HIPCHK(hipStreamSynchronize(rs[i]->stream));
+            }
+            HIPCHK(hipSetDevice(c->devices[0]));
+        } else {
+            // the same device more than once (rehearsal): RCCL allows one rank per device, so the blocks move by device copies
+            for (uint32_t i = 0; i < n; ++i) {
+                HIPCHK(hipSetDevice(c->devices[i]));
+                HIPCHK(hipStreamSynchronize(rs[i]->stream));
+            }
+            HIPCHK(hipSetDevice(c->devices[0]));
+            for (uint32_t i = 0; i < n; ++i) {
+                if (f32) HIPCHK(hipMemcpyAsync(c->d_gather_f32 + tile_px * i, rs[i]->d_f32, tile_px * 16, hipMemcpyDeviceToDevice, c->root_stream));
+                if (u8) HIPCHK(hipMemcpyAsync(c->d_gather_u8 + tile_px * i, rs[i]->d_u8, tile_px * 4, hipMemcpyDeviceToDevice, c->root_stream));
+            }
+        }
+        hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((frame_px + 255) / 256)), dim3(256), 0, c->root_stream, (uint32_t)W, (uint32_t)H, n, strip,
+                           rows_max, f32 ? c->d_gather_f32 : nullptr, u8 ? c->d_gather_u8 : nullptr, c->d_full_f32, c->d_full_u8);
+        HIPCHK(hipGetLastError());
+        if (rgba_f32) HIPCHK(hipMemcpyAsync(rgba_f32, c->d_full_f32, frame_px * 16, hipMemcpyDeviceToHost, c->root_stream));
+        if (rgba_u8) HIPCHK(hipMemcpyAsync(rgba_u8, c->d_full_u8, frame_px * 4, hipMemcpyDeviceToHost, c->root_stream));
+        HIPCHK(hipStreamSynchronize(c->root_stream));
+        return RT_OK;
+    });
+}
+
+} // extern "C"
+
+extern "C" {
 
 int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out) {
     if (!out || !state_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");

@@ -89,17 +89,20 @@ struct HipRendererBase : public IRenderer {
     std::string out_path = "out.png"; // src/util.hpp:27
     uint32_t russian_roulette = 0;    // extension, 0 = off (rt_renderer_set_russian_roulette)
     // Extension: more than one entry tiles the frame over these HIP devices in THIS process, one host thread per
-    // tile (interleaved 8-row strips, tile k -> devices[k]; the same device may appear more than once). The
-    // one-process-per-GPU RCCL path is rtamd/dist.py + bench.py; this one serves the CLI, whose image ends up in
-    // host memory for the PNG anyway.
+    // tile (interleaved 8-row strips, tile k -> devices[k]; the same device may appear more than once). Every tile is
+    // rendered into its renderer's own device buffer; rt_frame_gather then brings the strips to devices[0] with one
+    // grouped ncclGather over xGMI and de-interleaves them there: the frame touches host memory once, for the PNG.
+    // (The one-process-per-GPU form of the same gather is rtamd/dist.py + bench.py.)
     std::vector<int> devices;
     std::vector<rt_renderer*> tile_handles;
+    rt_comm* comm = nullptr;
     rt_stats last{};
 
     HipRendererBase(int kind, std::array<int32_t, 2> img_size, uint8_t* image, uint32_t max_depth, uint32_t sample_count)
         : img_size(img_size), image(image), max_depth(max_depth), sample_count(sample_count), kind(kind) {}
     ~HipRendererBase() override {
         for (rt_renderer* h : tile_handles) rt_renderer_destroy(h);
+        rt_comm_destroy(comm);
         rt_renderer_destroy(handle);
     }
 
@@ -116,8 +119,10 @@ struct HipRendererBase : public IRenderer {
             }
             bound = &scene;
         }
-        const size_t row_bytes = (size_t)img_size[0] * 4;
-        std::vector<std::vector<uint8_t>> part(G);
+        if (!comm) {
+            rt_check(rt_comm_create((int)G, devices.data(), &comm));
+            std::printf("Tile gather: %s\n", rt_comm_uses_rccl(comm) ? "RCCL ncclGather over xGMI" : "device copies (a device is listed twice: no RCCL rank per tile)");
+        }
         std::vector<rt_stats> st(G);
         std::vector<std::string> err(G);
         std::vector<std::thread> threads;
@@ -125,21 +130,19 @@ struct HipRendererBase : public IRenderer {
         for (uint32_t k = 0; k < G; ++k) {
             threads.emplace_back([&, k]() {
                 rt_renderer* h = tile_handles[k];
-                part[k].resize((size_t)rt_renderer_local_rows(h) * row_bytes + 4);
                 if (rt_renderer_set_russian_roulette(h, russian_roulette) != RT_OK ||
-                    rt_render_frame(h, &camera.c, nullptr, part[k].data(), &st[k]) != RT_OK)
+                    rt_render_frame_begin(h, &camera.c, nullptr, rt_renderer_tile_u8(h), nullptr) != RT_OK ||
+                    rt_render_frame_end(h, &st[k]) != RT_OK)
                     err[k] = rt_last_error(); // rt_last_error is per thread
             });
         }
         for (auto& t : threads) t.join();
-        const double wall = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         for (uint32_t k = 0; k < G; ++k)
             if (!err[k].empty()) throw std::runtime_error("librt_mi355x (tile " + std::to_string(k) + "): " + err[k]);
+        rt_check(rt_frame_gather(comm, tile_handles.data(), nullptr, image, 0, 0)); // strips -> root GPU -> full frame -> host, once
+        const double wall = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         last = rt_stats{};
         for (uint32_t k = 0; k < G; ++k) {
-            const int32_t rows = rt_renderer_local_rows(tile_handles[k]);
-            for (int32_t lr = 0; lr < rows; ++lr)
-                std::memcpy(image + (size_t)rt_renderer_global_row(tile_handles[k], lr) * row_bytes, part[k].data() + (size_t)lr * row_bytes, row_bytes);
             last.rays += st[k].rays;
             last.launches += st[k].launches;
             last.device_ms = std::max(last.device_ms, st[k].device_ms);

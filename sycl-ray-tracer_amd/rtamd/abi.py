@@ -126,6 +126,14 @@ PROTOTYPES = {
     "rt_render_frame": (C.c_int, [C.c_void_p, _P(rt_camera), _P(C.c_float), _P(C.c_uint8), _P(rt_stats)]),
     "rt_render_frame_device": (C.c_int, [C.c_void_p, _P(rt_camera), C.c_void_p, C.c_void_p, C.c_void_p,
                                          _P(rt_stats)]),
+    "rt_comm_create": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_void_p)]),
+    "rt_comm_destroy": (None, [C.c_void_p]),
+    "rt_comm_uses_rccl": (C.c_int, [C.c_void_p]),
+    "rt_renderer_tile_f32": (C.c_void_p, [C.c_void_p]),
+    "rt_renderer_tile_u8": (C.c_void_p, [C.c_void_p]),
+    "rt_frame_gather": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_float), _P(C.c_uint8), C.c_int, C.c_int]),
+    "rt_comm_frame_f32": (C.c_void_p, [C.c_void_p]),
+    "rt_comm_frame_u8": (C.c_void_p, [C.c_void_p]),
     "rt_probe_xorshift": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_uint32)]),
     "rt_probe_half_roundtrip": (C.c_int, [C.c_int, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_uint16)]),
     "rt_probe_scatter": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_float),

@@ -189,6 +189,51 @@ class WavefrontRenderer(IRenderer):
     KIND = abi.RT_RENDERER_WAVEFRONT
 
 
+class TileComm:
+    """One process driving several GPUs: the frame's interleaved strips are rendered by one renderer per device and brought to
+    the root device by ONE grouped ncclGather over xGMI + a de-interleave kernel (rt_comm_create / rt_frame_gather in the C ABI;
+    SURVEY §8e). With the same device listed more than once (a rehearsal of an N-GPU split on fewer GPUs) RCCL cannot be used
+    (one rank per device) and the strips move by device copies instead: `uses_rccl` tells which."""
+
+    def __init__(self, devices):
+        self._lib = abi.load_library()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        abi.check(self._lib.rt_comm_create(len(self.devices), arr, C.byref(self.h)))
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.rt_comm_uses_rccl(self.h))
+
+    def render_and_gather(self, renderers, camera: Camera, want_f32: bool = True, want_u8: bool = True):
+        """renderers[i] = tile (i, n) on devices[i]. All tiles are enqueued (each into its renderer's own device buffers, no
+        host copy), collected, gathered to the root and returned as (full rgba_f32 | None, full rgba_u8 | None, rays)."""
+        n = len(self.devices)
+        assert len(renderers) == n
+        for r in renderers:
+            r.begin_frame(camera, d_f32=self._lib.rt_renderer_tile_f32(r.h) if want_f32 else 0,
+                          d_u8=self._lib.rt_renderer_tile_u8(r.h) if want_u8 else 0)
+        rays = sum(r.end_frame().rays for r in renderers)
+        w, h = renderers[0].img_size
+        f = np.zeros((h, w, 4), np.float32) if want_f32 else None
+        b = np.zeros((h, w, 4), np.uint8) if want_u8 else None
+        hs = (C.c_void_p * n)(*[r.h for r in renderers])
+        abi.check(self._lib.rt_frame_gather(self.h, hs, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None, 0, 0))
+        return f, b, rays
+
+    def close(self):
+        if self.h:
+            self._lib.rt_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def assemble_tiles(parts: list[np.ndarray], height: int, world: int, strip_rows: int = 8) -> np.ndarray:
     """De-interleaves per-rank compact strip buffers (rank order) into the full frame."""
     w, ch = parts[0].shape[1], parts[0].shape[2]

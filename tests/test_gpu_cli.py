@@ -82,7 +82,7 @@ def test_cli_failures_are_reported_not_fatal(rtlib, tmp_path):
 
 
 @pytest.mark.parametrize("flag", ["-m", "-w"])
-def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, tmp_path, flag):
+def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, oracle, tmp_path, flag):
     """--devices A,B,C: interleaved 8-row strips, one host thread and one renderer per tile (here three tiles on the
     one GPU of the box, which exercises everything except a second physical device): the PNG and the ray count are
     those of the single-device run, and a device that does not exist is refused."""
@@ -90,8 +90,12 @@ def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, tmp_path, 
     common = ["-d", 6, "-s", 3, "--width", 200, "--height", 150, "--quiet", flag, REPO / "assets" / "cube.glb"]
     _, rays1 = _run(["--out", tmp_path / "one.png"] + common, tmp_path)
     out3, rays3 = _run(["--devices", "0,0,0", "--out", tmp_path / "three.png"] + common, tmp_path)
-    assert "Running on devices: 0 0 0" in out3
+    assert "Running on devices: 0 0 0" in out3 and "Tile gather: device copies" in out3  # one GPU here: no RCCL rank per tile
     assert rays3 == rays1
     np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "three.png")), np.asarray(Image.open(tmp_path / "one.png")))
+    exp_u8, exp_rays, _ = _oracle_frame(oracle, REPO / "assets" / "cube.glb", 200, 150,
+                                        abi.RT_RENDERER_MEGAKERNEL if flag == "-m" else abi.RT_RENDERER_WAVEFRONT, 6, 3)
+    assert rays3 == exp_rays
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "three.png")), exp_u8)  # gathered on the device, equal to the oracle
     p = subprocess.run([str(EXE), "--devices", "0,99", "-s", "1", str(REPO / "assets" / "cube.glb")], capture_output=True, text=True, cwd=tmp_path)
     assert p.returncode == 1 and "does not exist" in p.stdout

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from rtamd import abi, scenes
-from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer, assemble_tiles
+from rtamd.renderer import Camera, MegakernelRenderer, Scene, TileComm, WavefrontRenderer, assemble_tiles
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -264,6 +264,51 @@ def test_tile_split_union_equals_full_frame(gpu_scenes, cls, kind, world, strip)
     r.close()
     assert rays == full.rays
     np.testing.assert_array_equal(assemble_tiles(parts, h, world, strip), full.rgba_f32)
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+@pytest.mark.parametrize("devices", [(0, 0, 0), (0,), (0, 0, 0, 0, 0, 0, 0, 0)])
+def test_native_frame_gather_equals_the_single_device_frame(gpu_scenes, oracle, cls, kind, devices):
+    """rt_comm_create / rt_frame_gather (the library's own multi-GPU gather): every tile is rendered into its
+    renderer's device buffer, the strips are brought to the root device and de-interleaved there; the frame that comes back is
+    bit-identical to the single-device frame AND to the oracle, and the ray counts add up. On this one-GPU box a list that names
+    device 0 several times takes the device-copy path (RCCL allows one rank per device); the one-rank list (0,) takes the RCCL
+    path itself: ncclCommInitAll + grouped ncclGather on a communicator of size 1. Image height 93 is not a multiple of the
+    strip height, so the last strip is short and the ranks own different numbers of rows (ncclGather sends padded tiles)."""
+    gs = gpu_scenes("cornell")
+    w, h, depth, spp = 120, 93, 6, 3
+    cam = Camera.for_scene(gs.desc, (w, h))
+    ref = cls(gs, (w, h), depth, spp)
+    full = ref.render_frame(cam)
+    ref.close()
+    n = len(devices)
+    comm = TileComm(devices)
+    assert comm.uses_rccl == (n == 1)
+    rs = []
+    for k in range(n):
+        r = cls(gs, (w, h), depth, spp)
+        r.set_tile(k, n, 8)
+        rs.append(r)
+    for _ in range(2):  # the communicator and its root buffers are reusable
+        f, b, rays = comm.render_and_gather(rs, cam)
+        assert rays == full.rays
+        np.testing.assert_array_equal(f, full.rgba_f32)
+        np.testing.assert_array_equal(b, full.rgba_u8)
+    sd = gs.desc
+    of, ob, orays = oracle.OracleScene(sd).render(oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length), kind, depth, spp)
+    _assert_frames_equal(f, b, rays, of, ob, orays, f"gathered frame, {n} tiles")
+    # only the u8 plane (what the CLI asks for)
+    f2, b2, _ = comm.render_and_gather(rs, cam, want_f32=False)
+    assert f2 is None
+    np.testing.assert_array_equal(b2, full.rgba_u8)
+    # a renderer that is not tile (i, n) of the frame is refused, not gathered
+    if n > 1:
+        rs[1].set_tile(0, n, 8)
+        with pytest.raises(abi.RtError):
+            comm.render_and_gather(rs, cam)
+    for r in rs:
+        r.close()
+    comm.close()
 
 
 @pytest.mark.parametrize("cls,kind", KINDS)

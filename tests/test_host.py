@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(rtlib):
     for n in names:
         assert hasattr(rtlib, n), f"librt_mi355x.so does not export {n}"
         assert n in abi.PROTOTYPES, f"{n} has no ctypes prototype in rtamd/abi.py"
-    assert rtlib.rt_abi_version() == 3
+    assert rtlib.rt_abi_version() == 4
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -148,6 +148,12 @@ def test_gpu_entry_points_fail_loudly_without_a_device(rtlib, scene_cache):
     out = np.zeros(4, np.float32)
     st = C.c_uint32()
     assert rtlib.rt_probe_xorshift(0, 1, 4, abi.fptr(out), C.byref(st)) == abi.RT_ERR_NO_DEVICE
+    comm = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert rtlib.rt_comm_create(2, devs, C.byref(comm)) == abi.RT_ERR_NO_DEVICE and not comm.value
+    assert rtlib.rt_frame_gather(None, None, None, None, 1, 1) == abi.RT_ERR_INVALID
+    assert rtlib.rt_renderer_tile_f32(None) is None and rtlib.rt_comm_frame_u8(None) is None and rtlib.rt_comm_uses_rccl(None) == 0
+    rtlib.rt_comm_destroy(None)
     rtlib.rt_scene_destroy(hs)
 
 
