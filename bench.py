@@ -11,16 +11,27 @@ Both renderers of the path (wavefront, megakernel) are measured with the same K 
 faster one (`config.renderer`), `renderers` holds both with their rooflines.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak
+  roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak (the
+                 contractual figure: tiny by construction for a traversal kernel), `traffic` = FETCH_SIZE + WRITE_SIZE of that
+                 kernel, and `binding` = the bound that actually binds: VALU issue cycles against the ceiling measured for the
+                 kernel's own instruction mix (profiles/r02_valu_calibration.json). traffic and binding are MEASURED IN THIS RUN
+                 (N = 1): after the timed region bench.py renders one more frame of the same configuration in a child process
+                 under `rocprofv3 --pmc` (three passes: FETCH_SIZE+TCC_HIT, WRITE_SIZE+TCC_MISS, SQ VALU counters); if rocprofv3
+                 is not usable they fall back to the committed profiles/ files and say so in `source`.
   cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -35,10 +46,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 #   k_wf_shade                                : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B = 92 B/ray
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
-MEGAKERNEL_BYTES_PER_PIXEL = 20  # one fp32 RGBA store + one RGBA8 store per pixel per frame
+MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel per frame (the timed region stores no RGBA8 image)
 # SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 48-B triangle records, 124 B of hit shading;
-# the per-ray counts are the atrium's, measured with RT_KERNEL_STATS=1: 17.88 nodes, 4.52 triangles
-TRAVERSAL_BYTES_PER_RAY = 17.88 * 64 + 4.52 * 48 + 124
+# the per-ray counts are the atrium's, measured with RT_KERNEL_STATS=1 (gpurun_out/r02/stats_base.log): 17.10 nodes, 4.60 triangles
+TRAVERSAL_BYTES_PER_RAY = 17.10 * 64 + 4.60 * 48 + 124
 
 
 def main() -> int:
@@ -60,7 +71,11 @@ def main() -> int:
                          "time; 2 hides the end-of-frame drain of the per-pixel sample chains behind the next frame)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-frames-in-flight measurement")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes after the timed region")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # one frame, no timing: the process rocprofv3 wraps
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     import numpy as np
     import torch
@@ -176,22 +191,6 @@ def main() -> int:
             roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
             roof["note"] = ("the megakernel has no per-ray HBM stream (SURVEY.md §8d): its only algorithmic HBM traffic is the frame store; "
                             "its BVH gathers are served by L2 / Infinity Cache (profiles/r01_traffic.json)")
-        valu_file = REPO / "profiles" / "r01_valu.json"
-        if valu_file.exists():  # what actually bounds the kernel (PMC, measured once per round: rocprofv3 cannot run inside bench.py)
-            v = json.loads(valu_file.read_text()).get(kernel)
-            if v:
-                roof["valu_issue_busy"] = min(1.0, v["valu_issue_busy"])
-                roof["valu_lane_utilisation"] = v["lane_utilisation"]
-                roof["valu_note"] = ("SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * kernel cycles) and SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) "
-                                     "from profiles/r01_valu.json: the kernel is bound by VALU issue at this lane utilisation, not by HBM")
-        traffic_file = REPO / "profiles" / "r01_traffic.json"
-        if traffic_file.exists() and (W, H) == (1920, 1080) and world == 1:
-            t = json.loads(traffic_file.read_text()).get(kernel)  # PMC-measured (rocprofv3 cannot run inside bench.py)
-            if t:
-                scale = args.spp / 4.0 if name == "megakernel" else 1.0  # the megakernel profile is a 4-spp frame
-                roof["traffic"] = round(t["traffic_bytes_per_launch"] * scale, 1)
-                roof["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_traffic.json (separate rocprofv3 --pmc passes at "
-                                        "1080p); mostly BVH/triangle gathers served by the Infinity Cache, not re-reads of the ray stream")
         return {"renderer": name, "value": round(rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "rays_per_frame": int(rays_all / args.steps),
                 "device_ms_per_step": round(dev_ms / args.steps, 3), "roofline": roof}
@@ -224,6 +223,8 @@ def main() -> int:
                                            "ms_per_step": pipelined["ms_per_step"],
                                            "note": "same K frames with the next frame enqueued (second renderer + strip buffer) before the "
                                                    "current one is collected; not the headline: ms_per_step is then no longer one frame's latency"}
+        if world == 1:
+            attach_pmc(out["roofline"], best, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
         print(json.dumps(out), flush=True)
@@ -231,6 +232,104 @@ def main() -> int:
     if use_dist:
         dist.destroy_process_group()
     return 0
+
+
+def pmc_child(args):
+    """One untimed frame of the bench configuration (one renderer): the process `rocprofv3 --pmc ... --` wraps."""
+    from rtamd import abi, scenes
+    from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
+    sd = scenes.atrium_scene(args.detail)
+    scene = Scene(sd, device=0, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+    cam = Camera.for_scene(sd, (args.width, args.height))
+    cls = WavefrontRenderer if args.renderer == "wavefront" else MegakernelRenderer
+    r = cls(scene, (args.width, args.height), args.depth, args.spp)
+    fr = r.render_frame(cam, want_f32=False, want_u8=False)
+    print(json.dumps({"rays": fr.rays, "device_ms": fr.device_ms}), flush=True)
+    r.close()
+    scene.close()
+    return 0
+
+
+PMC_PASSES = (("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_MISS_sum"),
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"))
+
+
+def live_pmc(args, renderer, kernel):
+    """Counters of `kernel` over ONE frame of this very configuration, each pass in its own child process under rocprofv3 --pmc
+    (counters only: no trace domains). Returns {counter: sum over the kernel's launches, "launches": n} or raises."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists():
+        raise RuntimeError("rocprofv3 not found")
+    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--renderer", renderer, "--width", str(args.width), "--height", str(args.height),
+             "--spp", str(args.spp), "--depth", str(args.depth), "--detail", str(args.detail), "--bvh", args.bvh]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    sums, launches = {}, 0
+    for counters in PMC_PASSES:
+        with tempfile.TemporaryDirectory(prefix="rt_pmc_", dir="/tmp") as d:
+            p = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if p.returncode != 0 or not files:
+                raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr[-300:]}")
+            ids = set()
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel in row["Kernel_Name"]:
+                        sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                        ids.add(row["Dispatch_Id"])
+            launches = max(launches, len(ids))
+    sums["launches"] = launches
+    return sums
+
+
+def attach_pmc(roof, best, args):
+    """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds)."""
+    kernel, name = roof["kernel"], best["renderer"]
+    calib_file = REPO / "profiles" / "r02_valu_calibration.json"
+    calib = json.loads(calib_file.read_text()) if calib_file.exists() else {}
+    ceil_key = "k_megakernel_static_mix" if kernel == "k_megakernel" else "k_wf_extend_static_mix"
+    ceiling = calib.get("valu_ceiling_cycles_per_instruction", {}).get(ceil_key)
+    c, source = None, None
+    if not args.no_live_pmc:
+        try:
+            c = live_pmc(args, name, kernel)
+            source = "measured in this run: one more frame of the same configuration in a child process under rocprofv3 --pmc (3 passes)"
+        except Exception as e:  # no rocprofv3 / no counter access here: say so and use the committed profile of the same command
+            source = f"live rocprofv3 --pmc unavailable ({str(e)[:160]}); "
+    if c is None:
+        prof = REPO / "profiles" / "r02_pmc_bench.json"
+        if prof.exists():
+            c = json.loads(prof.read_text()).get(kernel)
+            source = (source or "") + "committed profiles/r02_pmc_bench.json (same command, scripts/final_profile.sh)"
+    if not c:
+        roof["traffic_note"] = (source or "") + "no counters available"
+        return
+    n = max(int(c.get("launches", 1)), 1)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0  # rocprofv3 reports both in KiB
+        roof["traffic"] = round((fetch + write) / n, 1)
+        roof["traffic_detail"] = {"fetch_bytes_per_launch": round(fetch / n, 1), "write_bytes_per_launch": round(write / n, 1),
+                                  "fetch_x2_upper_bound_per_launch": round((2 * fetch + write) / n, 1),
+                                  "bytes_per_ray": round((fetch + write) / max(best["rays_per_frame"], 1), 1),
+                                  "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4) if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum") else None}
+        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of the kernel, separate --pmc passes, KiB -> bytes. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts a wide "
+                                "coalesced 16 B/lane stream at half its bytes; these reads are scattered 64-byte node / 48-byte triangle gathers (uncalibrated width), so the "
+                                "raw figure is `traffic` and the x2 bound is given beside it. Infinity-Cache hits are included (the scene is MALL-resident): this is fabric "
+                                "traffic, far above the algorithmic bytes because a traversal kernel's real work is gathers, not its output stream.")
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c and ceiling:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+        per_simd = c["SQ_INSTS_VALU"] / 1024.0       # 256 CUs x 4 SIMDs
+        achieved_cpi = cycles / max(per_simd, 1.0)   # kernel cycles per VALU instruction a SIMD issued
+        roof["binding"] = {"bound": "valu_issue", "frac": round(ceiling / achieved_cpi, 4),
+                           "achieved_cycles_per_valu_instruction": round(achieved_cpi, 3), "ceiling_cycles_per_valu_instruction": ceiling,
+                           "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4) if c.get("SQ_ACTIVE_INST_VALU") else None,
+                           "valu_instructions_per_ray": round(c["SQ_INSTS_VALU"] / max(best["rays_per_frame"], 1), 1),
+                           "note": "frac = VALU issue cycles the kernel needs at the measured cost of its own instruction mix (profiles/r02_valu_calibration.json: a "
+                                   "wave64 VALU instruction costs 2, 4 or 8 cycles by opcode on gfx950) / kernel cycles. ~1 = the SIMDs issue VALU instructions "
+                                   "back to back: the kernel is bound by instruction issue at its lane utilisation, not by HBM, cache bandwidth or latency."}
+    roof["pmc_source"] = source
 
 
 def cpu_baseline(sd, W, H, depth, spp, renderer):

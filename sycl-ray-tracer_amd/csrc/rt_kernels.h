@@ -471,15 +471,81 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
 // terminates at most once per sample, so K5's "combined += image" needs no pass of its own) and compacts
 // the survivors into the next queue: wave64 __ballot + mbcnt prefix inside each wave, wave totals
 // combined through LDS, ONE global atomic per 256-thread block (the reference: one per 16 work-items).
+//
+// Ray re-ordering (the reference's compaction src/render_wavefront.cpp:282-311 keeps arrival order, its
+// PLAN.md:18-27 lists sorting as an idea). Two independent options, template flags, both off by default:
+//   REORDER  the block's survivors are written in the order of a 9-bit key = direction octant (3 bits) | 4x4x4 cell of the
+//            new origin in Morton order (6 bits): a counting sort through a 512-bin LDS histogram. The 256 slots a block
+//            writes are two of EXTEND's 128-slot chunks, so a chunk holds rays that start in neighbouring cells and head into
+//            the same octant.
+//   MATSORT  before shading, the block permutes its 256 (ray, hit) pairs by the hit's material kind (miss / diffuse /
+//            metallic / dielectric / none), so that a wave executes one branch of Material::scatter instead of three.
+// Neither changes any pixel: a pixel has at most one ray in flight, its accumulator and RNG word are touched by that ray only,
+// and the queue order is not part of the result (tests/test_gpu_parity.py::test_wavefront_reordering_keeps_the_frame).
+RT_DEV uint32_t reorder_key(const SceneDev& S, const RayState& r) {
+    auto cell = [&](float p, int a) {
+        const int c = (int)((p - S.cell_lo[a]) * S.cell_scale[a]);
+        return (uint32_t)(c < 0 ? 0 : (c > 3 ? 3 : c));
+    };
+    const uint32_t cx = cell(r.org.x, 0), cy = cell(r.org.y, 1), cz = cell(r.org.z, 2);
+    // 2-bit Morton interleave: x0 y0 z0 x1 y1 z1
+    const uint32_t morton = (cx & 1u) | ((cy & 1u) << 1) | ((cz & 1u) << 2) | ((cx >> 1) << 3) | ((cy >> 1) << 4) | ((cz >> 1) << 5);
+    const uint32_t oct = ((uint32_t)(r.dir[0] >> 15) & 1u) | (((uint32_t)(r.dir[1] >> 15) & 1u) << 1) | (((uint32_t)(r.dir[2] >> 15) & 1u) << 2); // half sign bits
+    return (oct << 6) | morton;
+}
+
+// exclusive prefix sum over 256 per-thread values (4 waves); returns this thread's offset, *total = the block's sum
+RT_DEV uint32_t block_scan_256(uint32_t v, uint32_t* wave_sums /* LDS, 4 */, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += o;
+    }
+    if (lane == 63u) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += wave_sums[w];
+    *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    return base + incl - v;
+}
+
+template <bool REORDER, bool MATSORT>
 __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, QueueDev qout, const float4* __restrict__ hits,
                                                    uint32_t* __restrict__ rng, float4* __restrict__ accum,
                                                    const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ count_out, int last_depth, int rr_active) {
     __shared__ uint32_t wave_total[4];
     __shared__ uint32_t block_base;
+    __shared__ uint32_t bins[REORDER ? 512 : 1];
+    __shared__ uint32_t perm[MATSORT ? 256 : 1];
+    __shared__ uint32_t kind_count[MATSORT ? 8 : 1];
     const uint32_t n = *count_in;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x * 256u >= n) return; // whole block idle (uniform exit)
+    if (MATSORT) {
+        // material kind of this thread's own slot (0 = miss, 1 + rt type otherwise, 7 = slot beyond the queue), then a counting sort of
+        // the block's slot indices by kind: thread t shades the slot at position t of the sorted order
+        uint32_t kind = 7u;
+        if (i < n) {
+            const uint32_t tri = __float_as_uint(hits[i].w);
+            kind = 0u;
+            if (tri != kNoTri) {
+                const uint32_t inst_id = S.shade[tri].instance;
+                kind = 1u + (S.mats[S.inst[inst_id].material].type & 3u);
+            }
+        }
+        if (threadIdx.x < 8u) kind_count[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t rank_in_kind = atomicAdd(&kind_count[kind], 1u);
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < kind; ++k) before += kind_count[k];
+        perm[before + rank_in_kind] = i;
+        __syncthreads();
+        i = perm[threadIdx.x];
+    }
     bool survive = false;
     RayState r{};
     uint32_t id = 0;
@@ -500,6 +566,26 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
             if (rr_active && survive) survive = roulette(st, r);
         }
         rng[id] = st;          // ScopedRng store
+    }
+    if (REORDER) {
+        // counting sort of the block's survivors by reorder_key: histogram, exclusive scan of the 512 bins (two per thread), scatter
+        bins[threadIdx.x] = 0u, bins[threadIdx.x + 256u] = 0u;
+        __syncthreads();
+        uint32_t key = 0, rank_in_bin = 0;
+        if (survive) {
+            key = reorder_key(S, r);
+            rank_in_bin = atomicAdd(&bins[key], 1u);
+        }
+        __syncthreads();
+        const uint32_t b0 = bins[2u * threadIdx.x], b1 = bins[2u * threadIdx.x + 1u];
+        uint32_t total = 0;
+        const uint32_t off = block_scan_256(b0 + b1, wave_total, &total);
+        if (threadIdx.x == 0) block_base = total ? atomicAdd(count_out, total) : 0u;
+        __syncthreads(); // every thread has read its two bins: they may be overwritten by their offsets now
+        bins[2u * threadIdx.x] = off, bins[2u * threadIdx.x + 1u] = off + b0;
+        __syncthreads();
+        if (survive) queue_store(qout, block_base + bins[key] + rank_in_bin, id, r);
+        return;
     }
     const unsigned long long mask = __ballot(survive);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

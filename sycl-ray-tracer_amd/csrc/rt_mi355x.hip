@@ -140,6 +140,10 @@ struct rt_renderer {
     CameraDev* d_cam = nullptr;
     CameraDev* h_cam = nullptr;
     bool use_graph = false;
+    // f-3: re-ordering of the ray queue between bounces, both OFF by default (measured: profiles/r02_reorder.json)
+    //   wf_reorder : SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the origin) before it writes them
+    //   wf_matsort : SHADE partitions a block's rays by material kind before shading them, so that a wave shades one kind
+    bool wf_reorder = false, wf_matsort = false;
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
     uint8_t* graph_u8 = nullptr;
@@ -316,9 +320,17 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     HIPCHK(hipEventRecord(e1, ls));
                     ne[k] += 2;
                 }
-                hipLaunchKernelGGL(k_wf_shade, dim3(grid[k]), dim3(256), 0, ls, S, L.q[buf[k]], L.q[buf[k] ^ 1], L.d_hits, L.d_rng,
-                                   L.d_accum, counts + d, counts + d + 1, d + 1 == D ? 1 : 0,
-                                   r->rr_start && d + 1 >= r->rr_start && d + 1 < D ? 1 : 0);
+                {
+                    const int last = d + 1 == D ? 1 : 0, rr = r->rr_start && d + 1 >= r->rr_start && d + 1 < D ? 1 : 0;
+#define RT_SHADE_LAUNCH(RE, MS)                                                                                                         \
+    hipLaunchKernelGGL((k_wf_shade<RE, MS>), dim3(grid[k]), dim3(256), 0, ls, S, L.q[buf[k]], L.q[buf[k] ^ 1], L.d_hits, L.d_rng, L.d_accum, \
+                       counts + d, counts + d + 1, last, rr)
+                    if (r->wf_reorder && r->wf_matsort) RT_SHADE_LAUNCH(true, true);
+                    else if (r->wf_reorder) RT_SHADE_LAUNCH(true, false);
+                    else if (r->wf_matsort) RT_SHADE_LAUNCH(false, true);
+                    else RT_SHADE_LAUNCH(false, false);
+#undef RT_SHADE_LAUNCH
+                }
                 launches += 2;
                 buf[k] ^= 1;
             }
@@ -601,6 +613,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
         s->dev.n_nodes = (uint32_t)s->hs.nodes.size();
         s->dev.n_tris = (uint32_t)(s->hs.wverts.size() / 9);
         std::memcpy(s->dev.sky, s->hs.sky, 12);
+        for (int a = 0; a < 3; ++a) {
+            const float ext = s->hs.bounds_hi[a] - s->hs.bounds_lo[a];
+            s->dev.cell_lo[a] = s->hs.bounds_lo[a];
+            s->dev.cell_scale[a] = ext > 0.0f && std::isfinite(ext) ? 4.0f / ext : 0.0f;
+        }
     }
     *out = s;
     return RT_OK;
@@ -698,6 +715,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';
     }
     rc = no_throw([&] { return alloc_tile_buffers(r); });
     if (rc != RT_OK) return bail(rc);

@@ -89,6 +89,7 @@ struct SceneDev {
     uint32_t n_nodes;
     uint32_t n_tris;
     float sky[3];
+    float cell_lo[3], cell_scale[3]; // ray re-ordering (f-3): cell = (origin - cell_lo) * cell_scale, 0..4 per axis over the scene's bounds
 };
 
 // == Camera POD (src/camera.hpp:65-72)

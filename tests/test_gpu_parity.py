@@ -311,6 +311,43 @@ def test_native_frame_gather_equals_the_single_device_frame(gpu_scenes, oracle, 
     comm.close()
 
 
+@pytest.mark.parametrize("reorder,matsort", [(1, 0), (0, 1), (1, 1)])
+def test_wavefront_reordering_keeps_the_frame(gpu_scenes, oracle, monkeypatch, reorder, matsort):
+    """SURVEY §8f row f-3, ray re-ordering between bounces (RT_WF_REORDER: the compaction bins survivors by direction octant and
+    4x4x4 origin cell; RT_WF_MATSORT: SHADE partitions its rays by material kind): the queue order is not part of the result,
+    so frame, unorm8 image and ray count stay bit-identical to the default order and to the oracle — also with Russian roulette,
+    whose extra RNG draw sits between shading and compaction."""
+    for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 4), ("atrium", {"detail": 1}, (256, 144), 10, 3)):
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        monkeypatch.delenv("RT_WF_REORDER", raising=False)
+        monkeypatch.delenv("RT_WF_MATSORT", raising=False)
+        base_r = WavefrontRenderer(gs, (w, h), depth, spp)
+        base = base_r.render_frame(cam)
+        base_r.set_russian_roulette(2)
+        base_rr = base_r.render_frame(cam)
+        base_r.close()
+        monkeypatch.setenv("RT_WF_REORDER", str(reorder))  # read by rt_renderer_create
+        monkeypatch.setenv("RT_WF_MATSORT", str(matsort))
+        r = WavefrontRenderer(gs, (w, h), depth, spp)
+        got = r.render_frame(cam)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, base.rgba_f32, base.rgba_u8, base.rays, f"{name} reorder={reorder} matsort={matsort}")
+        r.set_tile(1, 3, 8)  # an odd tile: short queues, blocks that are not full
+        tile = r.render_frame(cam)
+        r.set_tile(0, 1, 8)
+        r.set_russian_roulette(2)
+        got_rr = r.render_frame(cam)
+        _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, base_rr.rgba_f32, base_rr.rgba_u8, base_rr.rays, f"{name} rr")
+        r.close()
+        rows = [y for y in range(h) if (y // 8) % 3 == 1]
+        np.testing.assert_array_equal(tile.rgba_f32, base.rgba_f32[rows])
+        if name == "cornell":
+            f, b, rays = oracle.OracleScene(sd).render(oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length),
+                                                       abi.RT_RENDERER_WAVEFRONT, depth, spp)
+            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, "re-ordered wavefront vs oracle")
+
+
 @pytest.mark.parametrize("cls,kind", KINDS)
 def test_render_is_deterministic_and_reusable(gpu_scenes, cls, kind):
     gs = gpu_scenes("atrium", detail=1)
