@@ -276,7 +276,7 @@ int build_lbvh_gpu(HostScene& hs, const std::vector<TriRec>& gtris, std::string&
     uint32_t n_front = 1, level = 0;
     int cur = 0;
     while (n_front) {
-        if (++level > 64) { err = "internal: GPU LBVH deeper than 64 levels"; return RT_ERR_INVALID; }
+        if (++level > 64) { err = "GPU LBVH deeper than 64 levels"; return RT_ERR_UNSUPPORTED; } // the caller falls back to a balanced host build
         h_counters[1] = 0;
         LB_CHK(hipMemcpy(d_counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_emit, dim3((n_front + 127u) / 128u), dim3(128), 0, 0, n_front, d_front[cur], d_front[cur ^ 1], d_counters,

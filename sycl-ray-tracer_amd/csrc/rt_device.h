@@ -297,21 +297,25 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
     // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 costs
     // 4 cycles per pair, the same as two v_fma_f32.)
+    // The inversion alone is not a proof: when the camera is hundreds of scene diameters away, 255 * scale * inv can be absorbed by
+    // the rounding of origin * inv - o * inv on all three axes, entry == exit, and a ray through the node's corner would "hit" the
+    // absent child, whose word (kChildEmpty == kTravDone) ends the traversal. Slots 1..3 (slot 0 always holds a child) are therefore
+    // also tested for kChildEmpty: one v_cmp per slot into an SGPR pair, combined with the hit mask on the scalar unit.
+    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
     float k0, k1, k2, k3;
-#define RT_CHILD(K, CVT)                                                                                  \
+#define RT_CHILD(K, CVT, PRESENT)                                                                         \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
                                          __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
-        K = sel(lanes(tn <= tf), inf, tn);                                                               \
+        K = sel(lanes(tn <= tf) & (PRESENT), inf, tn);                                                   \
     }
-    RT_CHILD(k0, ub0)
-    RT_CHILD(k1, ub1)
-    RT_CHILD(k2, ub2)
-    RT_CHILD(k3, ub3)
+    RT_CHILD(k0, ub0, ~0ull)
+    RT_CHILD(k1, ub1, lanes(c1 != kChildEmpty))
+    RT_CHILD(k2, ub2, lanes(c2 != kChildEmpty))
+    RT_CHILD(k3, ub3, lanes(c3 != kChildEmpty))
 #undef RT_CHILD
-    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
     // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
     // SGPR pair + four e64 selects on it (18 cycles).
 #define RT_CE(KA, CA, KB, CB)                                                        \
@@ -455,17 +459,20 @@ RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
 // :127-156). Returns false when the path is absorbed.
 RT_DEV bool scatter(const SceneDev& S, const MatRec& m, uint32_t& rng, f3 dir, f3 normal, float u, float v,
                     f3& out_dir, f3& out_att) {
-    if (m.type == RT_MAT_DIFFUSE) {
-        out_dir = normal + rng_unit_vector(rng);
-        if (near_zero3(dir)) out_dir = normal; // tests the incoming direction, as the reference does
+    // Diffuse (:72-86) and metallic (:98-110) share everything that is expensive — the three RNG draws + normalisation of
+    // random_unit_vector and the albedo fetch — so they run as ONE instruction stream with the per-material operands selected:
+    // a shading round of ~48 lanes nearly always holds both kinds, and two separate branches would execute that code twice.
+    // Per lane the operations and their order are exactly those of its own material's body.
+    if (m.type == RT_MAT_DIFFUSE || m.type == RT_MAT_METALLIC) {
+        const bool diffuse = m.type == RT_MAT_DIFFUSE;
+        const f3 unit = rng_unit_vector(rng);
+        const f3 reflected = reflect3(dir, normal);                        // used by the metallic lanes only
+        const f3 base = diffuse ? normal : reflected;
+        const f3 offs = diffuse ? unit : m.roughness * unit;                // diffuse: normal + unit; metallic: reflected + roughness * unit
+        out_dir = base + offs;
+        if (diffuse && near_zero3(dir)) out_dir = normal;                   // tests the incoming direction, as the reference does
         out_att = albedo(S, m, u, v);
-        return true;
-    }
-    if (m.type == RT_MAT_METALLIC) {
-        f3 reflected = reflect3(dir, normal);
-        out_dir = reflected + m.roughness * rng_unit_vector(rng);
-        out_att = albedo(S, m, u, v);
-        return dot3(out_dir, normal) > 0.0f;
+        return diffuse ? true : dot3(out_dir, normal) > 0.0f;
     }
     if (m.type == RT_MAT_DIELECTRIC) {
         out_att = mk3(1.0f, 1.0f, 1.0f);

@@ -187,6 +187,14 @@ void free_tile_buffers(rt_renderer* r) {
     r->lanes.clear();
 }
 
+// waits for everything queued on the renderer's streams (its own, the wavefront lanes', and `extra` if given)
+void drain_streams(rt_renderer* r, hipStream_t extra) {
+    if (extra) (void)hipStreamSynchronize(extra);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (auto& L : r->lanes)
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+}
+
 int32_t rows_of_tile(const TileDev& t, int32_t height) {
     int32_t rows = 0;
     for (int32_t y = 0; y < height; ++y)
@@ -444,7 +452,14 @@ int frame_begin(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
     r->pending_t0 = std::chrono::high_resolution_clock::now();
     HIPCHK(hipEventRecord(r->ev_begin, st));
     int rc = enqueue_frame(r, cam, d_f32, d_u8, st, &r->pending_stats, &r->pending_hot);
-    if (rc != RT_OK) return rc;
+    if (rc != RT_OK) {
+        // part of the frame may already be queued (on `st` and on the wavefront lanes' streams): nothing may still be running on the
+        // tile buffers when the caller reacts to the error (set_tile / destroy free them), so drain before reporting it
+        const std::string msg = g_err;
+        drain_streams(r, st);
+        g_err = msg;
+        return rc;
+    }
     HIPCHK(hipEventRecord(r->ev_end, st));
     r->pending_stream = st;
     r->frame_pending = true;
@@ -727,8 +742,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
 void rt_renderer_destroy(rt_renderer* r) {
     if (!r) return;
     if (r->scene && hipSetDevice(r->scene->device) == hipSuccess) {
-        if (r->frame_pending && r->pending_stream) (void)hipStreamSynchronize(r->pending_stream);
-        if (r->stream) (void)hipStreamSynchronize(r->stream);
+        drain_streams(r, r->pending_stream);
         free_tile_buffers(r);
         if (r->d_cam) (void)hipFree(r->d_cam);
         if (r->h_cam) (void)hipHostFree(r->h_cam);
@@ -746,7 +760,7 @@ int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t
     if (world == 0 || rank >= world || strip_rows == 0) return fail(RT_ERR_INVALID, "bad tile split");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     HIPCHK(hipSetDevice(r->scene->device));
-    HIPCHK(hipStreamSynchronize(r->stream));
+    drain_streams(r, r->pending_stream); // the queues are about to be freed: nothing may be running on any of the renderer's streams
     r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
     return no_throw([&] { return alloc_tile_buffers(r); });
 }

@@ -378,7 +378,7 @@ bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)
             uint32_t lo_b = 0, hi_b = 0;
             bool ok = true;
             for (int k = 0; k < 4 && ok; ++k) {
-                uint32_t ql = 255, qh = 0; // absent child: inverted (never decoded as a hit: child word says empty)
+                uint32_t ql = 255, qh = 0; // absent child: inverted box; the kernel also tests the child word of slots 1..3 for kChildEmpty
                 if (k < nk) {
                     double fl = std::floor(((double)klo[k][a] - (double)nlo[a]) / (double)s);
                     double fh = std::ceil(((double)khi[k][a] - (double)nlo[a]) / (double)s);
@@ -531,10 +531,36 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
 
     if (bvh_kind == RT_BVH_LBVH_GPU && T >= 8) { // whole build on the device (lbvh_gpu.hip); tiny scenes use the host
         int rc = build_lbvh_gpu(hs, gtris, err);
+        if (rc == RT_ERR_UNSUPPORTED) { // degenerate Morton order (deeper than the emission loop allows): balanced host fallback
+            err.clear();
+            return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err);
+        }
         if (rc != RT_OK) return rc;
         hs.stack_need = need(0);
-        if (hs.stack_need + 1 < (uint32_t)kStackSize) return RT_OK;
-        return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // degenerate Morton order: balanced host fallback
+        if (hs.stack_need + 1 >= (uint32_t)kStackSize) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err);
+        // surface-area cost of the downloaded tree (the diagnostic rt_scene_info reports for the host builders too): every node's
+        // children boxes decoded, inner child 1 step x area, leaf child (triangles) x area, relative to the root's area
+        {
+            double cost = 0.0, root_area = 0.0;
+            for (size_t i = 0; i < hs.nodes.size(); ++i) {
+                const BvhNode& n = hs.nodes[i];
+                float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int k = 0; k < 4; ++k) {
+                    if (n.child[k] == kChildEmpty) continue;
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = n.origin[a] + (float)((n.q[2 * a] >> (8 * k)) & 0xffu) * n.scale(a);
+                        hi[a] = n.origin[a] + (float)((n.q[2 * a + 1] >> (8 * k)) & 0xffu) * n.scale(a);
+                        nlo[a] = std::min(nlo[a], lo[a]), nhi[a] = std::max(nhi[a], hi[a]);
+                    }
+                    const double w = n.child[k] >= 0 ? 1.0 : (double)(((uint32_t)~n.child[k] & 3u) + 1u);
+                    cost += w * (double)half_area(lo, hi);
+                }
+                if (i == 0) root_area = (double)half_area(nlo, nhi);
+            }
+            hs.sah_cost = root_area > 0.0 ? 1.0 + cost / root_area : 0.0;
+        }
+        return RT_OK;
     }
 
     Builder b(hs.wverts);

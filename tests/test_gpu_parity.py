@@ -547,6 +547,42 @@ def test_config5_as_stated_tile_0_of_8(gpu_scenes, scene_cache, oracle, cls, kin
                                     what=f"config 5 {cls.__name__}")
 
 
+@pytest.mark.parametrize("bvh", [abi.RT_BVH_SAH, abi.RT_BVH_LBVH, abi.RT_BVH_LBVH_GPU])
+def test_far_away_ray_origins_equal_brute_force(oracle, scene_cache, bvh):
+    """with the ray origin hundreds to millions of scene diameters away, the quantised child planes of a node collapse to
+    one t value (255 * scale / d is absorbed by the rounding of (origin - o) / d), so an ABSENT child's inverted box no longer tests
+    as a miss by itself; the kernel must still never enter it (its word would end the traversal early). Exact diagonals through the
+    cube's corners and centre (equal slab distances on all three axes) and random far origins, against the CPU brute force."""
+    sd = scene_cache("cube")
+    gs, osc = Scene(sd, 0, bvh), oracle.OracleScene(sd)
+    tw = sd.world_triangles().reshape(-1, 3)
+    lo, hi = tw.min(0), tw.max(0)
+    c, ext = (lo + hi) / 2, float((hi - lo).max())
+    rng = np.random.default_rng(11)
+    org, dirs = [], []
+    for dist in (3.0, 7e2, 1e4, 1e6, 3e7):
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    d = np.array([sx, sy, sz], np.float64)
+                    for target in (c, lo, hi, c + 0.25 * ext * d):
+                        org.append(target - d * dist * ext), dirs.append(d)
+                        org.append(target - d * dist * ext), dirs.append(d * 1e-3)   # unnormalised, as the renderers store them
+        t = rng.uniform(lo, hi, (200, 3))
+        d = rng.normal(size=(200, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        org.extend(t - d * dist * ext), dirs.extend(d)
+    org, dirs = np.asarray(org, np.float32), np.asarray(dirs, np.float32)
+    gt, gu, gv, gtri = gs.intersect(org, dirs)
+    et, eu, ev, etri = osc.intersect(org, dirs, use_bvh=False)
+    np.testing.assert_array_equal(gtri, etri)
+    np.testing.assert_array_equal(gt, et)
+    np.testing.assert_array_equal(gu, eu)
+    np.testing.assert_array_equal(gv, ev)
+    assert (gtri != NO_TRI).sum() > 100
+    gs.close()
+
+
 def _soup_scene(rng, n_tris, scale=1.0, offset=(0, 0, 0), duplicates=0, degenerate=0, n_inst=3):
     """Random triangle soup spread over several rotated/scaled instances, with exact duplicate triangles (equal t:
     the lowest global index must win) and zero-area triangles (must never be hit)."""
