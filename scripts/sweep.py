@@ -19,7 +19,7 @@ if not glb.exists():
     export_glb(scenes.atrium_scene(4), glb)
 depth_samples = [(10, 128), (20, 128), (30, 128), (40, 128), (50, 128), (10, 32), (10, 128), (10, 256), (10, 512)]  # benchmark.py:6-18
 renderers = ["-m", "-w"]
-scene = "./assets/atrium4.glb (generated Sponza stand-in, 283,084 triangles)"
+scene = "./assets/atrium4.glb"  # the generated Sponza stand-in (283,084 triangles); no comma inside a CSV column
 hdr = "renderer,depth,samples,scene,time,rays_per_sec,ray_count\n"
 (out / "benchmark_raw.csv").write_text(hdr)
 (out / "benchmark_avg.csv").write_text(hdr)
