@@ -46,6 +46,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 #   k_wf_shade                                : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B = 92 B/ray
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
+# The wavefront renderer's default schedule (RT_WF_FINISH_DEPTH=0): one compacted queue per sample, written by
+# k_wf_generate (34 B state + 4 B RNG r/w + count) and consumed by k_wf_finish, which follows every path to its end in registers:
+#   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
+FINISH_BYTES_PER_PATH = 74
 MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel per frame (the timed region stores no RGBA8 image)
 # SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 48-B triangle records, 124 B of hit shading;
 # the per-ray counts are the atrium's, measured with RT_KERNEL_STATS=1 (gpurun_out/r02/stats_base.log): 17.10 nodes, 4.60 triangles
@@ -171,7 +175,10 @@ def main() -> int:
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
             elapsed, rays_all = float(mx[0]), float(sm[0])
         # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch time
-        if name == "wavefront":
+        finish_depth = int(os.environ.get("RT_WF_FINISH_DEPTH", "0"))
+        if name == "wavefront" and finish_depth < args.depth:  # the profiled launches are k_wf_finish: one per sample and stream lane
+            kernel, bytes_per_launch = "k_wf_finish", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
+        elif name == "wavefront":
             kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
         else:
             kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
@@ -181,11 +188,15 @@ def main() -> int:
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": hot_launches,
                 "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1)}
         if name == "wavefront":
-            frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
-            roof["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
-            roof["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
+            if kernel == "k_wf_extend":
+                frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
+                roof["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
+                roof["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
+            else:
+                roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
+                roof["schedule"] = f"RT_WF_FINISH_DEPTH={finish_depth}: generate -> compacted queue -> k_wf_finish per sample"
             roof["concurrent_streams"] = 2  # two sub-tiles on two streams: a launch shares the chip with its twin
-            roof["note"] = "incoherent BVH traversal is bound by gather latency and VALU issue; the HBM fraction is small by construction (DESIGN.md §6)"
+            roof["note"] = "incoherent BVH traversal is bound by VALU issue at its lane utilisation; the HBM fraction is small by construction (DESIGN.md §6)"
         else:
             roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache
             roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
@@ -289,7 +300,7 @@ def attach_pmc(roof, best, args):
     kernel, name = roof["kernel"], best["renderer"]
     calib_file = REPO / "profiles" / "r02_valu_calibration.json"
     calib = json.loads(calib_file.read_text()) if calib_file.exists() else {}
-    ceil_key = "k_megakernel_static_mix" if kernel == "k_megakernel" else "k_wf_extend_static_mix"
+    ceil_key = "k_wf_extend_static_mix" if kernel == "k_wf_extend" else "k_megakernel_static_mix"  # k_wf_finish is the megakernel's loop
     ceiling = calib.get("valu_ceiling_cycles_per_instruction", {}).get(ceil_key)
     c, source = None, None
     if not args.no_live_pmc:

@@ -141,7 +141,11 @@ int rt_scene_check_bvh(const rt_scene* scene);
 /* Closest-hit query for a batch of rays: the replacement for rtcIntersect1 at
  * src/trace_ray.hpp:18-27 (tnear = 1e-4, tfar = +inf, no culling, no masks).
  * org/dir: 3*n floats (host). Outputs (host, n each): t (+inf on miss), u, v and
- * tri = global triangle index in rt_scene_desc order (0xFFFFFFFF on miss). */
+ * tri = global triangle index in rt_scene_desc order (0xFFFFFFFF on miss).
+ * Range of the contract: the result equals the brute-force closest hit over all triangles (same fp32 Moller-Trumbore) for ray
+ * origins within 100 scene diameters of the scene's bounds — every ray the renderers generate. Farther out the fp32 error of
+ * the ray itself (~1e-7 x |origin|) exceeds the padding of the BVH boxes (2e-5 x scene scale) and a hit that only exists by
+ * that error may be culled. */
 int rt_intersect_batch(rt_scene* scene, uint32_t n, const float* org, const float* dir, float* t,
                        float* u, float* v, uint32_t* tri);
 

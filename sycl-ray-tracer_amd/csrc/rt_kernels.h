@@ -604,6 +604,118 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
     }
 }
 
+// ---- FINISH: the rest of every path of the sample in ONE launch ------------------------------------------------------------
+// The reference pays one shoot_rays launch (here: EXTEND + SHADE) per bounce whatever the queue holds
+// (src/render_wavefront.cpp:396-417). After the first `first_depth` bounces — wide, coherent, worth a dense SHADE and a global
+// compaction each — this kernel takes the compacted queue of bounce `first_depth` and follows every ray in it to the end of its
+// path: persistent waves pull 128-slot chunks of the queue exactly as EXTEND does (__ballot + mbcnt ranks, one atomic per chunk),
+// a lane traverses, shades (the same shade_bounce as SHADE), and either continues with the scattered ray in registers or adds the
+// path's clamped result to the accumulator, stores the pixel's RNG word and takes the next queue slot. Per pixel the operations
+// and their order are exactly SHADE's (per-sample clamp, black survivors of the last depth, roulette between shading and
+// compaction), so the frame is bit-identical for every first_depth (tests: test_wavefront_finish_depth_keeps_the_frame).
+// What it removes: (max_depth - first_depth) x 2 dependent launches per sample with their drain tails, the hit-record round trip
+// and the 68 B/ray queue write + read of every later bounce. Rays traced beyond bounce `first_depth` are counted into *extra_rays
+// (the queue lengths the host sums stop at first_depth).
+template <bool STATS>
+__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, QueueDev qin, const uint32_t* __restrict__ count_in,
+                                                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ rng_buf,
+                                                                    float4* __restrict__ accum, uint32_t* __restrict__ extra_rays,
+                                                                    uint32_t first_depth, uint32_t max_depth, uint32_t rr_start,
+                                                                    unsigned long long* __restrict__ stats_out) {
+    WaveStats ws;
+    const uint32_t n = *count_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t kWavesPerBlock = RT_MEGA_BLOCK / 64;
+    const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
+    Trav T;
+    T.cur = kTravDone;
+    bool live = false;
+    RayState r{};
+    uint32_t id = 0, rng = 0, depth = 0, rays = 0;
+    uint32_t chunk_pos = wave_id * kExtendChunk; // first chunk static, later ones from the cursor (as EXTEND)
+    uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
+    bool exhausted = chunk_pos >= n;
+    if (exhausted) return;
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long idle_m = __ballot(!live);
+            const uint32_t cnt = (uint32_t)__popcll(idle_m);
+            if (cnt >= RT_MEGA_REFILL) {
+                if (chunk_pos == chunk_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, kExtendChunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * kExtendChunk;
+                    if (base >= n) exhausted = true;
+                    chunk_pos = base;
+                    chunk_end = base + kExtendChunk < n ? base + kExtendChunk : n;
+                }
+                if (!exhausted) {
+                    const uint32_t avail = chunk_end - chunk_pos;
+                    const uint32_t take = cnt < avail ? cnt : avail;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                    if (!live && rank < take) {
+                        id = queue_load(qin, chunk_pos + rank, r);
+                        rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register to the end of the path
+                        depth = first_depth;
+                        trav_begin(T, r.org, ray_dir(r));
+                        live = true;
+                    }
+                    chunk_pos += take;
+                }
+            }
+        }
+        const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+        if (n_live == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
+            const bool waiting = live && T.cur == kTravDone;
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+#pragma unroll
+            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+        }
+#if RT_MEGA_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
+            if (depth > first_depth) rays++; // the rays of bounce first_depth are the queue's length, already in the host's sum
+            f3 res;
+            const bool done = shade_bounce(S, rng, r, T.best, res);
+            depth++;
+            bool ends = done;
+            if (done) {
+                float4 acc = accum[id];
+                acc.x = acc.x + clamp01(res.x), acc.y = acc.y + clamp01(res.y), acc.z = acc.z + clamp01(res.z);
+                accum[id] = acc;
+            } else if (depth == max_depth) {
+                ends = true; // survivors of the last depth contribute (0,0,0) (:279-280)
+            } else if (rr_start && depth >= rr_start) {
+                ends = !roulette(rng, r);
+            }
+            if (ends) {
+                rng_buf[id] = rng; // ScopedRng store
+                live = false;
+            } else {
+                trav_begin(T, r.org, ray_dir(r));
+            }
+        }
+#if RT_MEGA_PRIO == 2
+        __builtin_amdgcn_s_setprio(2);
+#endif
+    }
+    const uint32_t total = wave_sum_u32(rays);
+    if (lane == 0 && total) atomicAdd(extra_rays, total);
+    if (STATS && lane == 0) {
+        atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
+        atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
+        atomicAdd(stats_out + 7, (unsigned long long)ws.top_lanes);
+    }
+}
+
 // ---- K6 + K7: mean over samples, sqrt gamma, fp32 + unorm8 outputs ------------------------------------
 __global__ void __launch_bounds__(256) k_wf_resolve(uint32_t n_local, uint32_t spp, uint32_t width, uint32_t strip_rows,
                                                      uint32_t n_lanes, uint32_t lane_index, const float4* __restrict__ accum,

@@ -22,6 +22,15 @@
 
 using namespace rt;
 
+// Schedule of the wavefront renderer (measured, atrium 1080p 8 spp, Mrays/s): every bounce as its own EXTEND + SHADE launch pair (the
+// reference's schedule) 5103; first 1 / 2 / 3 / 4 / 6 bounces that way, the rest of each path in k_wf_finish 4923 / 4772 / 4942 / 4873 / 5028;
+// everything in k_wf_finish (one compacted queue per sample: generate -> queue -> persistent waves) 5282 when each of the two
+// overlapping launches asks for all 6 wave slots per SIMD, 6086 when each asks for its half. BASELINE config 5's tile (4K, depth 16):
+// 56.8 ms -> 39.2 ms against the megakernel's 30.9. Default: 0 bounces launch by launch.
+#ifndef RT_WF_FINISH_DEPTH_DEFAULT
+#define RT_WF_FINISH_DEPTH_DEFAULT 0u
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -144,6 +153,10 @@ struct rt_renderer {
     //   wf_reorder : SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the origin) before it writes them
     //   wf_matsort : SHADE partitions a block's rays by material kind before shading them, so that a wave shades one kind
     bool wf_reorder = false, wf_matsort = false;
+    // bounces rendered launch by launch (EXTEND + SHADE) before k_wf_finish follows the surviving rays to the end of their paths in
+    // one launch per sample; >= max_depth = the reference's schedule (a launch pair per bounce). RT_WF_FINISH_DEPTH overrides.
+    uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
+    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
     uint8_t* graph_u8 = nullptr;
@@ -305,7 +318,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                                L.d_counts + (size_t)s * (D + 1));
             launches++;
         }
-        for (uint32_t d = 0; d < D; ++d) {
+        const uint32_t D0 = std::min(D, r->wf_finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
+        for (uint32_t d = 0; d < D0; ++d) {
             for (uint32_t k = 0; k < K; ++k) {
                 auto& L = r->lanes[k];
                 if (L.n_local == 0) continue;
@@ -313,7 +327,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (r->profile_kernels) {
+                if (r->profile_kernels && D0 == D) {
                     e0 = pool_event(L.ev_pool, ne[k]), e1 = pool_event(L.ev_pool, ne[k] + 1);
                     if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
                     HIPCHK(hipEventRecord(e0, ls));
@@ -324,7 +338,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 else
                     hipLaunchKernelGGL(k_wf_extend<false>, dim3(ext_grid[k]), dim3(RT_EXTEND_BLOCK), 0, ls, S, L.q[buf[k]], L.d_hits,
                                        counts + d, cursors + (size_t)s * D + d, (unsigned long long*)nullptr);
-                if (r->profile_kernels) {
+                if (r->profile_kernels && D0 == D) {
                     HIPCHK(hipEventRecord(e1, ls));
                     ne[k] += 2;
                 }
@@ -341,6 +355,41 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 }
                 launches += 2;
                 buf[k] ^= 1;
+            }
+        }
+        if (D0 < D) {
+            constexpr uint32_t fin_wpb = RT_MEGA_BLOCK / 64;
+            for (uint32_t k = 0; k < K; ++k) {
+                auto& L = r->lanes[k];
+                if (L.n_local == 0) continue;
+                hipStream_t ls = L.stream;
+                uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
+                uint32_t* cursors = L.d_counts + L.h_counts.size();
+                // persistent grid: wf_finish_occ waves per SIMD for THIS launch. The lanes' launches overlap on the device, so each asks for
+                // its share of the SIMDs' wave slots rather than all of them: fewer, longer-lived waves follow more paths per lane
+                // (less idling at the end of each wave's last paths) and the streams' kernels are resident side by side.
+                const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
+                                                                                    (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K))));
+                const uint32_t fin_grid = (fin_waves + fin_wpb - 1u) / fin_wpb;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (r->profile_kernels) { // the dominant kernel of this schedule
+                    e0 = pool_event(L.ev_pool, ne[k]), e1 = pool_event(L.ev_pool, ne[k] + 1);
+                    if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                    HIPCHK(hipEventRecord(e0, ls));
+                }
+                // rays traced beyond bounce D0 go into counts[D0 + 1] (no queue of that depth exists: the host's sum over d < D takes it)
+                uint32_t* extra = counts + std::min(D0 + 1u, D);
+                if (r->d_stats)
+                    hipLaunchKernelGGL(k_wf_finish<true>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, L.q[buf[k]], counts + D0, cursors + (size_t)s * D + D0,
+                                       L.d_rng, L.d_accum, extra, D0, D, r->rr_start, r->d_stats);
+                else
+                    hipLaunchKernelGGL(k_wf_finish<false>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, L.q[buf[k]], counts + D0, cursors + (size_t)s * D + D0,
+                                       L.d_rng, L.d_accum, extra, D0, D, r->rr_start, (unsigned long long*)nullptr);
+                if (r->profile_kernels) {
+                    HIPCHK(hipEventRecord(e1, ls));
+                    ne[k] += 2;
+                }
+                launches++;
             }
         }
     }
@@ -730,6 +779,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) r->wf_finish_depth = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';
     }
