@@ -228,8 +228,11 @@ int alloc_tile_buffers(rt_renderer* r) {
     const size_t n_pad = std::max<size_t>((size_t)rows_of_tile(t0, r->height) * (size_t)r->width, n);
     HIPCHK(hipMalloc((void**)&r->d_f32, n_pad * 16));
     HIPCHK(hipMalloc((void**)&r->d_u8, n_pad * 4));
-    HIPCHK(hipMemset(r->d_f32, 0, n_pad * 16));
-    HIPCHK(hipMemset(r->d_u8, 0, n_pad * 4));
+    // the padding rows are gathered too: defined bytes. On the renderer's own stream: a hipMemset on the null stream is not ordered
+    // against this non-blocking stream and could land on top of the first frame.
+    HIPCHK(hipMemsetAsync(r->d_f32, 0, n_pad * 16, r->stream));
+    HIPCHK(hipMemsetAsync(r->d_u8, 0, n_pad * 4, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors
     } else {
