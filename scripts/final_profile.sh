@@ -1,17 +1,22 @@
 #!/bin/bash
-# Round-end evidence (run on the GPU box from the repo root): the default bench line, the same command under
-# rocprofv3 --kernel-trace --stats, and the separate PMC passes behind profiles/r01_traffic.json.
+# Round-end evidence (run on the GPU box from the repo root; outputs under gpurun_out/r02/final, copied into profiles/ by scripts/collect_profiles.py):
+#   1. the VALU calibration with the CURRENT kernels' instruction mixes (scripts/gen_valu_mix.py must have been run on the current build)
+#   2. the default bench line (which measures traffic + the VALU-issue bound itself, in child processes under rocprofv3 --pmc)
+#   3. the same command under rocprofv3 --kernel-trace --stats (average launch duration of the dominant kernels)
+#   4. PMC passes of one frame per renderer at the bench configuration (the fallback file bench.py reads when rocprofv3 is not usable)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-timeout -k 10 500 python3 bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
+out=gpurun_out/r02/final; mkdir -p $out
+bash scripts/valu_calib.sh > $out/calib.log 2>&1
+echo calib done
+timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo bench done
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -- python3 bench.py --no-cpu-baseline > gpurun_out/final/bench_under_rocprof.json 2> gpurun_out/final/kt.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-live-pmc > $out/bench_under_rocprof.json 2> $out/kt.err
 echo ktrace done
-for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "hit TCC_HIT_sum" "miss TCC_MISS_sum"; do
-  set -- $pass
-  for rend in wavefront megakernel; do
-    timeout -k 5 150 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/final/pmc_${rend}_$1 -- python3 bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline --no-pipelined --renderer $rend > gpurun_out/final/pmc_${rend}_$1.log 2>&1
-    echo "pmc $rend $1 rc=$?"
+for rend in megakernel wavefront; do
+  for pass in "fetch FETCH_SIZE TCC_HIT_sum" "write WRITE_SIZE TCC_MISS_sum" "valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" "wave SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU" "lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD"; do
+    set -- $pass; tag=$1; shift
+    timeout -k 5 200 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_${rend}_$tag -- python3 bench.py --pmc-child --renderer $rend > $out/pmc_${rend}_$tag.log 2>&1
+    echo "pmc $rend $tag rc=$?"
   done
 done
