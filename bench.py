@@ -298,10 +298,19 @@ def live_pmc(args, renderer, kernel):
 def attach_pmc(roof, best, args):
     """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds)."""
     kernel, name = roof["kernel"], best["renderer"]
-    calib_file = REPO / "profiles" / "r02_valu_calibration.json"
-    calib = json.loads(calib_file.read_text()) if calib_file.exists() else {}
-    ceil_key = "k_wf_extend_static_mix" if kernel == "k_wf_extend" else "k_megakernel_static_mix"  # k_wf_finish is the megakernel's loop
-    ceiling = calib.get("valu_ceiling_cycles_per_instruction", {}).get(ceil_key)
+    # VALU issue ceiling of the kernel's DYNAMIC instruction mix: its three step kinds (inner node / whole leaf / shading round) priced
+    # opcode by opcode with the calibrated issue costs and weighted with the measured steps per ray (scripts/phase_cost.py ->
+    # profiles/r02_phase_cost.json; k_wf_finish and k_wf_extend run the same steps). The static whole-kernel mix of
+    # profiles/r02_valu_calibration.json over-weights the long, rarely executed shading code and is only the fallback.
+    ceiling, ceiling_source = None, None
+    phase_file, calib_file = REPO / "profiles" / "r02_phase_cost.json", REPO / "profiles" / "r02_valu_calibration.json"
+    if phase_file.exists():
+        ceiling = json.loads(phase_file.read_text()).get("per_ray", {}).get("dynamic_ceiling_cycles_per_instruction")
+        ceiling_source = "profiles/r02_phase_cost.json (dynamic mix: steps per ray x calibrated cost of each step kind)"
+    if ceiling is None and calib_file.exists():
+        ceil_key = "k_wf_extend_static_mix" if kernel == "k_wf_extend" else "k_megakernel_static_mix"
+        ceiling = json.loads(calib_file.read_text()).get("valu_ceiling_cycles_per_instruction", {}).get(ceil_key)
+        ceiling_source = "profiles/r02_valu_calibration.json (static whole-kernel mix)"
     c, source = None, None
     if not args.no_live_pmc:
         try:
@@ -335,11 +344,13 @@ def attach_pmc(roof, best, args):
         achieved_cpi = cycles / max(per_simd, 1.0)   # kernel cycles per VALU instruction a SIMD issued
         roof["binding"] = {"bound": "valu_issue", "frac": round(ceiling / achieved_cpi, 4),
                            "achieved_cycles_per_valu_instruction": round(achieved_cpi, 3), "ceiling_cycles_per_valu_instruction": ceiling,
+                           "ceiling_source": ceiling_source,
                            "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4) if c.get("SQ_ACTIVE_INST_VALU") else None,
                            "valu_instructions_per_ray": round(c["SQ_INSTS_VALU"] / max(best["rays_per_frame"], 1), 1),
                            "note": "frac = VALU issue cycles the kernel needs at the measured cost of its own instruction mix (profiles/r02_valu_calibration.json: a "
                                    "wave64 VALU instruction costs 2, 4 or 8 cycles by opcode on gfx950) / kernel cycles. ~1 = the SIMDs issue VALU instructions "
-                                   "back to back: the kernel is bound by instruction issue at its lane utilisation, not by HBM, cache bandwidth or latency."}
+                                   "back to back: the kernel is bound by instruction issue at its lane utilisation, not by HBM, cache bandwidth or latency. The mix model is good to a "
+                                   "few percent (it prices every conditional push of an inner step), so a value slightly above 1 reads as 1; nothing is clamped."}
     roof["pmc_source"] = source
 
 

@@ -33,4 +33,7 @@ for rend in ("megakernel", "wavefront"):
 (P / "r02_pmc_bench.json").write_text(json.dumps(pmc, indent=1))
 out = subprocess.run([sys.executable, str(REPO / "scripts" / "valu_calib_summary.py")], capture_output=True, text=True, check=True).stdout
 (P / "r02_valu_calibration.json").write_text(out)
+stats_log = F / "stats.log"  # RT_KERNEL_STATS=1 frame of the final kernels (scripts/final_profile.sh)
+out = subprocess.run([sys.executable, str(REPO / "scripts" / "phase_cost.py")] + ([str(stats_log)] if stats_log.exists() else []), capture_output=True, text=True, check=True).stdout
+(P / "r02_phase_cost.json").write_text(out)
 print(open(P / "r02_bench.json").read()[:600])

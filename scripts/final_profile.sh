@@ -9,6 +9,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r02/final; mkdir -p $out
 bash scripts/valu_calib.sh > $out/calib.log 2>&1
 echo calib done
+RT_KERNEL_STATS=1 python3 scripts/quick_bench.py 8 mega > $out/stats.log 2>&1
+echo stats done
 timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo bench done
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-live-pmc > $out/bench_under_rocprof.json 2> $out/kt.err
