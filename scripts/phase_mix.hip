@@ -10,7 +10,7 @@ using namespace rt;
 extern "C" __global__ void __launch_bounds__(512, 6) phase_inner(SceneDev S, uint32_t n, float* out) {
     RT_TRAVERSAL_LDS(512)
     Trav T;
-    trav_begin(T, mk3(out[threadIdx.x], out[threadIdx.x + 1], out[threadIdx.x + 2]), mk3(out[threadIdx.x + 3], out[threadIdx.x + 4], out[threadIdx.x + 5]));
+    trav_begin(T, mk3(out[threadIdx.x], out[threadIdx.x + 1], out[threadIdx.x + 2]), mk3(out[threadIdx.x + 3], out[threadIdx.x + 4], out[threadIdx.x + 5]), stack);
     for (uint32_t i = 0; i < n; ++i) {
         if (T.cur >= 0) trav_inner(S, T, stack, top);
         asm volatile("; --- phase_inner step boundary" ::: "memory");
@@ -22,7 +22,7 @@ extern "C" __global__ void __launch_bounds__(512, 6) phase_inner(SceneDev S, uin
 extern "C" __global__ void __launch_bounds__(512, 6) phase_leaf(SceneDev S, uint32_t n, float* out) {
     RT_TRAVERSAL_LDS(512)
     Trav T;
-    trav_begin(T, mk3(out[threadIdx.x], out[threadIdx.x + 1], out[threadIdx.x + 2]), mk3(out[threadIdx.x + 3], out[threadIdx.x + 4], out[threadIdx.x + 5]));
+    trav_begin(T, mk3(out[threadIdx.x], out[threadIdx.x + 1], out[threadIdx.x + 2]), mk3(out[threadIdx.x + 3], out[threadIdx.x + 4], out[threadIdx.x + 5]), stack);
     for (uint32_t i = 0; i < n; ++i) {
         T.cur = ~(int32_t)(((i + threadIdx.x) << 2) | (threadIdx.x & 3u));
         trav_leaf<true>(S, T, stack);
@@ -37,6 +37,7 @@ extern "C" __global__ void __launch_bounds__(512, 6) phase_shade(SceneDev S, Cam
     uint32_t rng = threadIdx.x * 9781u + 1u, s = 0, depth = 0;
     f3 color = mk3(0, 0, 0);
     Trav T;
+    const TravStack stack{threadIdx.x * 4u, nullptr, 2048u};
     r.org = mk3(out[threadIdx.x], out[threadIdx.x + 1], out[threadIdx.x + 2]);
     r.dir[0] = (uint16_t)threadIdx.x, r.dir[1] = 0x3c00, r.dir[2] = 0xbc00;
     for (uint32_t i = 0; i < n; ++i) {
@@ -56,7 +57,7 @@ extern "C" __global__ void __launch_bounds__(512, 6) phase_shade(SceneDev S, Cam
                 s = 0;
             }
         }
-        trav_begin(T, r.org, ray_dir(r));
+        trav_begin(T, r.org, ray_dir(r), stack);
         out[threadIdx.x + i] = T.ix + T.ox;
         asm volatile("; --- phase_shade round boundary" ::: "memory");
     }

@@ -163,10 +163,12 @@ struct Trav {
     float ox, oy, oz;     // -o/d
     Hit best;
     int32_t cur;
-    int32_t sp;
+    uint32_t sp; // LDS byte address of the lane's next free stack entry (TravStack::base = empty); beyond the LDS part it keeps counting
 };
 
-RT_DEV void trav_begin(Trav& T, f3 o, f3 d) {
+struct TravStack;
+RT_DEV uint32_t stack_base(const TravStack& st);
+RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
     T.o = o, T.d = d;
     T.best.t = __builtin_huge_valf();
     T.best.u = T.best.v = 0.0f;
@@ -180,31 +182,53 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d) {
     T.ix = __builtin_amdgcn_rcpf(dx), T.iy = __builtin_amdgcn_rcpf(dy), T.iz = __builtin_amdgcn_rcpf(dz);
     T.ox = -o.x * T.ix, T.oy = -o.y * T.iy, T.oz = -o.z * T.iz;
     T.cur = 0; // root
-    T.sp = 0;
+    T.sp = stack_base(st); // empty stack
 }
 
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (entry-major, lane-minor:
 // conflict-free ds_read/ds_write_b32), deeper entries spill to per-lane scratch (rare). The first
 // version kept the whole stack in scratch: every push/pop was an L1 access and a write to HBM.
+// The stack pointer IS the LDS byte address of the next free entry (round 2): a push is ds_write + one v_add_u32, a pop one
+// v_sub_u32 + ds_read, with no index -> address arithmetic (v_lshl_or_b32 is a 4-cycle instruction) and no per-push depth test:
+// a step asks ONCE, wave-uniformly, whether every lane's next three pushes and its pop stay inside the LDS part (they nearly
+// always do) and only otherwise takes the general routines, which turn the address back into an entry index.
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 12
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;
 typedef __attribute__((address_space(3))) int32_t lds_i32; // forces ds_read/ds_write (never flat_*)
 struct TravStack {
-    lds_i32* lds;   // this lane's column: entry e at lds[e * stride]
+    uint32_t base;  // LDS byte address of this lane's entry 0
     int32_t* spill; // kStackSize - kLdsStack entries of scratch
-    int stride;     // threads per block
+    uint32_t pitch; // bytes from one entry of a lane to its next: 4 * threads per block (a power of two)
 };
-RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) {
-    if (T.sp < kLdsStack) st.lds[T.sp * st.stride] = v;
-    else st.spill[T.sp - kLdsStack] = v;
-    T.sp++;
+RT_DEV uint32_t stack_base(const TravStack& st) { return st.base; }
+RT_DEV lds_i32* lds_at(uint32_t addr) { return (lds_i32*)(size_t)addr; }
+// true when the lane's next `pushes` pushes and a pop all stay inside the LDS part of its stack
+RT_DEV bool stack_shallow(const TravStack& st, const Trav& T, uint32_t pushes) { return T.sp <= st.base + ((uint32_t)kLdsStack - pushes) * st.pitch; }
+RT_DEV void stk_push_lds(const TravStack& st, Trav& T, int32_t v) { // caller: stack_shallow
+    *lds_at(T.sp) = v;
+    T.sp += st.pitch;
 }
-RT_DEV void trav_pop(Trav& T, const TravStack& st) {
-    if (T.sp > 0) {
-        T.sp--;
-        T.cur = T.sp < kLdsStack ? st.lds[T.sp * st.stride] : st.spill[T.sp - kLdsStack];
+RT_DEV void trav_pop_lds(Trav& T, const TravStack& st) { // caller: stack_shallow
+    if (T.sp != st.base) {
+        T.sp -= st.pitch;
+        T.cur = *lds_at(T.sp);
+    } else {
+        T.cur = kTravDone;
+    }
+}
+RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) { // any depth
+    const uint32_t e = (T.sp - st.base) / st.pitch;
+    if (e < (uint32_t)kLdsStack) *lds_at(T.sp) = v;
+    else st.spill[e - (uint32_t)kLdsStack] = v;
+    T.sp += st.pitch;
+}
+RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
+    if (T.sp != st.base) {
+        T.sp -= st.pitch;
+        const uint32_t e = (T.sp - st.base) / st.pitch;
+        T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
     } else {
         T.cur = kTravDone;
     }
@@ -272,8 +296,18 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 // VALU budget of one step (cycles per wave, from the calibrated costs: fma/mul 2, everything else 4): 3 mul + 3 fma 12, sign selects
 // 3 cmp + 6 sel 36, per child 6 cvt + 6 fma + max/max3 + min/min3 + cmp + sel 60 (x4 = 240), sort RT_SORT_CE x (cmp + 4 sel) 20 each,
 // pushes / pop ~60: ~420 with the 5-comparator network, ~380 with the 3-comparator one.
+// Two experiments kept behind flags, both bit-exact, both OFF (megakernel, atrium 1080p 16 spp, two runs each, default 7040 / 7039 Mrays/s):
+//   RT_SIGN_XOR=1    near / far plane words picked with v_ashrrev + xor / and instead of v_cmp + v_cndmask: 7047 / 7071 (noise)
+//   RT_LEAF_UNROLL=1 whole-leaf step unrolled over two register sets (no record copies, -100 static issue cycles): 6975 / 6944 (-1.2 %)
+#ifndef RT_SIGN_XOR
+#define RT_SIGN_XOR 0
+#endif
+#ifndef RT_LEAF_UNROLL
+#define RT_LEAF_UNROLL 0
+#endif
 #ifndef RT_SORT_CE
-#define RT_SORT_CE 5 // 5: full sorting network. 3: nearest child exact, the (at most three) pushed ones in network order only
+#define RT_SORT_CE 4 // 5: full sorting network. 4 (default): nearest and farthest exact, the middle two in either order (-18 issue cycles per
+                     // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3: only the nearest exact (+-0)
 #endif
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top) {
     u32x4 w0, w1, w2, chw;
@@ -289,32 +323,44 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     const float bx = __builtin_fmaf(__uint_as_float(w0.x), T.ix, T.ox);
     const float by = __builtin_fmaf(__uint_as_float(w0.y), T.iy, T.oy);
     const float bz = __builtin_fmaf(__uint_as_float(w0.z), T.iz, T.oz);
+#if RT_SIGN_XOR
+    // near / far plane words by the direction sign without compares or selects: m = all ones where the component is negative
+    // (v_ashrrev_i32, 2 cycles), d = (lo ^ hi) & m, near = lo ^ d, far = hi ^ d — ten 2-cycle instructions per axis pair instead of
+    // one v_cmp + two v_cndmask (12 cycles)
+    const uint32_t mx = (uint32_t)(__float_as_int(T.ix) >> 31), my = (uint32_t)(__float_as_int(T.iy) >> 31), mz = (uint32_t)(__float_as_int(T.iz) >> 31);
+    const uint32_t dx = (w1.x ^ w1.y) & mx, dy = (w1.z ^ w1.w) & my, dz = (w2.x ^ w2.y) & mz;
+    const uint32_t qnx = w1.x ^ dx, qfx = w1.y ^ dx;
+    const uint32_t qny = w1.z ^ dy, qfy = w1.w ^ dy;
+    const uint32_t qnz = w2.x ^ dz, qfz = w2.y ^ dz;
+#else
     const lmask nx = lanes(T.ix < 0.0f), ny = lanes(T.iy < 0.0f), nz = lanes(T.iz < 0.0f);
     const uint32_t qnx = sel(nx, w1.x, w1.y), qfx = sel(nx, w1.y, w1.x);
     const uint32_t qny = sel(ny, w1.z, w1.w), qfy = sel(ny, w1.w, w1.z);
     const uint32_t qnz = sel(nz, w2.x, w2.y), qfz = sel(nz, w2.y, w2.x);
+#endif
     const float inf = __builtin_huge_valf();
     // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
     // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 costs
     // 4 cycles per pair, the same as two v_fma_f32.)
-    // The inversion alone is not a proof: when the camera is hundreds of scene diameters away, 255 * scale * inv can be absorbed by
-    // the rounding of origin * inv - o * inv on all three axes, entry == exit, and a ray through the node's corner would "hit" the
-    // absent child, whose word (kChildEmpty == kTravDone) ends the traversal. Slots 1..3 (slot 0 always holds a child) are therefore
-    // also tested for kChildEmpty: one v_cmp per slot into an SGPR pair, combined with the hit mask on the scalar unit.
+    // The inversion holds for every ray inside the contract's range (origins within 100 scene diameters, include/rt_mi355x.h:
+    // rt_intersect_batch). It would take an origin more than ~660 diameters away for 255 * scale * inv to be absorbed by the rounding
+    // of origin * inv - o * inv on all three axes at once (entry == exit), and out there the padded boxes are no longer conservative
+    // for any child, absent or not — so the child words are not tested here (an explicit kChildEmpty test per slot was measured at
+    // 12 issue cycles of ~500 per step).
     int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
     float k0, k1, k2, k3;
-#define RT_CHILD(K, CVT, PRESENT)                                                                         \
+#define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
                                          __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
-        K = sel(lanes(tn <= tf) & (PRESENT), inf, tn);                                                   \
+        K = sel(lanes(tn <= tf), inf, tn);                                                               \
     }
-    RT_CHILD(k0, ub0, ~0ull)
-    RT_CHILD(k1, ub1, lanes(c1 != kChildEmpty))
-    RT_CHILD(k2, ub2, lanes(c2 != kChildEmpty))
-    RT_CHILD(k3, ub3, lanes(c3 != kChildEmpty))
+    RT_CHILD(k0, ub0)
+    RT_CHILD(k1, ub1)
+    RT_CHILD(k2, ub2)
+    RT_CHILD(k3, ub3)
 #undef RT_CHILD
     // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
     // SGPR pair + four e64 selects on it (18 cycles).
@@ -328,18 +374,27 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     RT_CE(k0, c0, k1, c1)
     RT_CE(k2, c2, k3, c3)
     RT_CE(k0, c0, k2, c2)
-#if RT_SORT_CE >= 5
-    RT_CE(k1, c1, k3, c3)
-    RT_CE(k1, c1, k2, c2)
-#else
-    // after three comparators k0 is the minimum; hits are no longer a prefix of (k1, k2, k3), each is tested on its own below
+#if RT_SORT_CE >= 4
+    RT_CE(k1, c1, k3, c3) // four comparators: k0 the minimum, k3 the maximum, k1 / k2 in either order
 #endif
+#if RT_SORT_CE >= 5
+    RT_CE(k1, c1, k2, c2)
+#endif
+    // with fewer than five comparators the hits are no longer a sorted prefix of (k1, k2, k3): each is tested on its own below
 #undef RT_CE
-    if (k3 < inf) stk_push(stack, T, c3); // farthest first (exactly so with the full network)
-    if (k2 < inf) stk_push(stack, T, c2);
-    if (k1 < inf) stk_push(stack, T, c1);
-    if (k0 < inf) T.cur = c0;
-    else trav_pop(T, stack);
+    if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
+        if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
+        if (k2 < inf) stk_push_lds(stack, T, c2);
+        if (k1 < inf) stk_push_lds(stack, T, c1);
+        if (k0 < inf) T.cur = c0;
+        else trav_pop_lds(T, stack);
+    } else {
+        if (k3 < inf) stk_push(stack, T, c3);
+        if (k2 < inf) stk_push(stack, T, c2);
+        if (k1 < inf) stk_push(stack, T, c1);
+        if (k0 < inf) T.cur = c0;
+        else trav_pop(T, stack);
+    }
 }
 
 // leaf step. BATCH = false: ONE triangle of the leaf per step, then the next one or pop (rt_intersect_batch).
@@ -352,6 +407,34 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
+#if RT_LEAF_UNROLL
+        // Unrolled by hand over two register sets (A, B) so that no record is ever copied: the rolled loop moved the prefetched
+        // record into the "current" registers every iteration, 25 v_mov_b64 = ~100 of the step's ~900 issue cycles. Every branch
+        // condition is wave-uniform (a ballot): the step runs as many tests as the largest leaf among its lanes.
+        const float4* p4 = reinterpret_cast<const float4*>(S.tris + first);
+#define RT_LOAD_TRI(K, A_, B_, C_) A_ = p4[3 * (K)], B_ = p4[3 * (K) + 1], C_ = *reinterpret_cast<const float2*>(p4 + 3 * (K) + 2)
+        float4 aA, bA, aB, bB;
+        float2 cA, cB;
+        RT_LOAD_TRI(0, aA, bA, cA);
+        const bool more1 = __ballot(rem >= 1u) != 0ull;
+        if (more1) {
+            aB = aA, bB = bA, cB = cA; // lanes without a triangle 1 re-read nothing: defined values, never tested
+            if (rem >= 1u) RT_LOAD_TRI(1, aB, bB, cB);
+        }
+        tri_test_regs(aA, bA, cA, T.o, T.d, T.best);
+        if (more1) {
+            const bool more2 = __ballot(rem >= 2u) != 0ull;
+            if (more2 && rem >= 2u) RT_LOAD_TRI(2, aA, bA, cA);
+            if (rem >= 1u) tri_test_regs(aB, bB, cB, T.o, T.d, T.best);
+            if (more2) {
+                const bool more3 = __ballot(rem >= 3u) != 0ull;
+                if (more3 && rem >= 3u) RT_LOAD_TRI(3, aB, bB, cB);
+                if (rem >= 2u) tri_test_regs(aA, bA, cA, T.o, T.d, T.best);
+                if (more3 && rem >= 3u) tri_test_regs(aB, bB, cB, T.o, T.d, T.best);
+            }
+        }
+#undef RT_LOAD_TRI
+#else
         const float4* p4 = reinterpret_cast<const float4*>(S.tris + first);
         float4 a = p4[0], b = p4[1];
         float2 c = *reinterpret_cast<const float2*>(p4 + 2);
@@ -365,7 +448,9 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
             a = na, b = nb, c = nc;
         }
         if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
-        trav_pop(T, stack);
+#endif
+        if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
+        else trav_pop(T, stack);
     } else {
         tri_test(S.tris + first, T.o, T.d, T.best);
         if (rem) T.cur = ~(int32_t)(((first + 1u) << 2) | (rem - 1u));
@@ -401,7 +486,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 // run to completion (rt_intersect_batch; lanes that finish early wait for the wave)
 RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, const TravStack& stack, const TopTree& top) {
     Trav T;
-    trav_begin(T, o, d);
+    trav_begin(T, o, d, stack);
     while (trav_step_wave(S, T, stack, top)) {}
     return T.best;
 }

@@ -50,7 +50,7 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
     __syncthreads();                                                                                   \
     const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
-    const TravStack stack{(lds_i32*)(lds_stack + threadIdx.x), spill, (BLOCK)};
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                         color = mk3(0.0f, 0.0f, 0.0f);
                         s = 0, depth = 0;
                         r = camera_ray(cam, x, gy, rng);
-                        trav_begin(T, r.org, ray_dir(r));
+                        trav_begin(T, r.org, ray_dir(r), stack);
                         live = true;
                     }
                 }
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                                                                  ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
                 }
             }
-            if (live) trav_begin(T, r.org, ray_dir(r));
+            if (live) trav_begin(T, r.org, ray_dir(r), stack);
         }
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
 #if RT_MEGA_PRIO == 1
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
         // for a whole traversal step of the other lanes instead of stalling the wave at the request
         if (pending) {
             const f3 d = mk3(h2f((uint16_t)pend_a.x), h2f((uint16_t)(pend_a.x >> 16)), h2f((uint16_t)pend_a.y));
-            trav_begin(T, mk3(pend_o.x, pend_o.y, pend_o.z), d);
+            trav_begin(T, mk3(pend_o.x, pend_o.y, pend_o.z), d, stack);
             pending = false;
         }
         const bool need = T.cur == kTravDone; // finished or empty lane
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                         id = queue_load(qin, chunk_pos + rank, r);
                         rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register to the end of the path
                         depth = first_depth;
-                        trav_begin(T, r.org, ray_dir(r));
+                        trav_begin(T, r.org, ray_dir(r), stack);
                         live = true;
                     }
                     chunk_pos += take;
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 rng_buf[id] = rng; // ScopedRng store
                 live = false;
             } else {
-                trav_begin(T, r.org, ray_dir(r));
+                trav_begin(T, r.org, ray_dir(r), stack);
             }
         }
 #if RT_MEGA_PRIO == 2

@@ -378,7 +378,7 @@ bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)
             uint32_t lo_b = 0, hi_b = 0;
             bool ok = true;
             for (int k = 0; k < 4 && ok; ++k) {
-                uint32_t ql = 255, qh = 0; // absent child: inverted box; the kernel also tests the child word of slots 1..3 for kChildEmpty
+                uint32_t ql = 255, qh = 0; // absent child: inverted box = a miss for every ray inside the contract's range (rt_device.h, trav_inner)
                 if (k < nk) {
                     double fl = std::floor(((double)klo[k][a] - (double)nlo[a]) / (double)s);
                     double fh = std::ceil(((double)khi[k][a] - (double)nlo[a]) / (double)s);
