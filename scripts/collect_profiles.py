@@ -6,6 +6,9 @@ REPO = Path(__file__).resolve().parent.parent
 F, P = REPO / "gpurun_out" / "r02" / "final", REPO / "profiles"
 shutil.copy(F / "bench.json", P / "r02_bench.json")
 shutil.copy(F / "bench_under_rocprof.json", P / "r02_bench_under_rocprof.json")
+for name in ("config_table.txt", "tile_scaling.txt"):
+    if (F / name).exists():
+        shutil.copy(F / name, P / ("r02_" + name))
 stats = sorted(glob.glob(str(F / "kt" / "**" / "*kernel_stats.csv"), recursive=True))
 if stats:
     rows = list(csv.reader(open(stats[-1])))

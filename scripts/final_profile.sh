@@ -10,6 +10,8 @@ out=gpurun_out/r02/final; mkdir -p $out
 bash scripts/valu_calib.sh > $out/calib.log 2>&1
 echo calib done
 RT_KERNEL_STATS=1 python3 scripts/quick_bench.py 8 mega > $out/stats.log 2>&1
+python3 scripts/config_table.py > $out/config_table.txt 2>&1
+python3 scripts/tile_scaling.py 64 "" 1,2,4,8 > $out/tile_scaling.txt 2>&1
 echo stats done
 timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo bench done

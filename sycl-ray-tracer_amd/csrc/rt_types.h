@@ -31,7 +31,10 @@ struct alignas(64) BvhNode {
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 constexpr int32_t kChildEmpty = (int32_t)0x80000000;
 
-constexpr int kMaxLeafTris = 4;
+#ifndef RT_MAX_LEAF_TRIS
+#define RT_MAX_LEAF_TRIS 4
+#endif
+constexpr int kMaxLeafTris = RT_MAX_LEAF_TRIS; // 1..4 (the leaf code keeps count - 1 in two bits)
 constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64
 constexpr uint32_t kNoTri = 0xFFFFFFFFu;
 constexpr float kTNear = 0.0001f;   // RayData::to_embree tnear (src/camera.hpp:50)
