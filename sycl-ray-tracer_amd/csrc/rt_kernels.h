@@ -616,11 +616,17 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 // What it removes: (max_depth - first_depth) x 2 dependent launches per sample with their drain tails, the hit-record round trip
 // and the 68 B/ray queue write + read of every later bounce. Rays traced beyond bounce `first_depth` are counted into *extra_rays
 // (the queue lengths the host sums stop at first_depth).
+// n_samples > 1 (only with first_depth == 0): the streaming schedule. A pixel's samples are sequential (its RNG word), but pixels
+// are independent, so the lane whose path has ended generates the SAME pixel's next camera ray itself — Camera::get_ray with the RNG
+// word it holds in a register, exactly what k_wf_generate would do after reading that word back from memory — and goes on, for
+// n_samples samples, before it stores the word and takes the next queue slot. This removes the per-sample launch boundary and its
+// drain tail as well (the queue then feeds only the chunk's first sample).
 template <bool STATS>
-__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, QueueDev qin, const uint32_t* __restrict__ count_in,
-                                                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ rng_buf,
-                                                                    float4* __restrict__ accum, uint32_t* __restrict__ extra_rays,
-                                                                    uint32_t first_depth, uint32_t max_depth, uint32_t rr_start,
+__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
+                                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
+                                                                    uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
+                                                                    uint32_t* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
+                                                                    uint32_t n_samples, uint32_t rr_start,
                                                                     unsigned long long* __restrict__ stats_out) {
     WaveStats ws;
     const uint32_t n = *count_in;
@@ -634,6 +640,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     bool live = false;
     RayState r{};
     uint32_t id = 0, rng = 0, depth = 0, rays = 0;
+    uint32_t samples_left = 0;  // samples of this lane's pixel still to render in this launch, the current one included
+    bool first_counted = false; // the current path's first ray is a queue entry (counted by the host as the queue's length)
     uint32_t chunk_pos = wave_id * kExtendChunk; // first chunk static, later ones from the cursor (as EXTEND)
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
     bool exhausted = chunk_pos >= n;
@@ -657,8 +665,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                     if (!live && rank < take) {
                         id = queue_load(qin, chunk_pos + rank, r);
-                        rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register to the end of the path
+                        rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
                         depth = first_depth;
+                        samples_left = n_samples, first_counted = true;
                         trav_begin(T, r.org, ray_dir(r), stack);
                         live = true;
                     }
@@ -682,7 +691,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         __builtin_amdgcn_s_setprio(0);
 #endif
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
-            if (depth > first_depth) rays++; // the rays of bounce first_depth are the queue's length, already in the host's sum
+            if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum
             f3 res;
             const bool done = shade_bounce(S, rng, r, T.best, res);
             depth++;
@@ -695,6 +704,13 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 ends = true; // survivors of the last depth contribute (0,0,0) (:279-280)
             } else if (rr_start && depth >= rr_start) {
                 ends = !roulette(rng, r);
+            }
+            if (ends && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
+                const CameraDev cam = *camp;
+                const int x = (int)(id % (uint32_t)cam.width), ly = (int)(id / (uint32_t)cam.width);
+                r = camera_ray(cam, x, tile_global_row(tile, ly), rng);
+                depth = 0, first_counted = false;
+                ends = false;
             }
             if (ends) {
                 rng_buf[id] = rng; // ScopedRng store

@@ -30,6 +30,13 @@ using namespace rt;
 #ifndef RT_WF_FINISH_DEPTH_DEFAULT
 #define RT_WF_FINISH_DEPTH_DEFAULT 0u
 #endif
+// Samples k_wf_finish renders per pixel and launch (streaming: the lane generates the pixel's next camera ray itself). Measured, atrium
+// 1080p 16 spp: 1 / 2 / 4 / 8 / 16 samples per launch = 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s (megakernel 6965); config 5's tile
+// 40.3 / - / 42.8 / 43.8 / 43.0 ms. Fewer launch boundaries, but a lane then holds its pixel for the whole chunk and the launch ends
+// with its slowest pixel-chunk: the tail grows as fast as the boundaries vanish. Default 1: one launch per sample.
+#ifndef RT_WF_SAMPLES_PER_LAUNCH_DEFAULT
+#define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 1u
+#endif
 
 namespace {
 
@@ -132,7 +139,7 @@ struct rt_renderer {
         float4* d_accum = nullptr;
         uint32_t* d_counts = nullptr; // spp * (max_depth + 1) queue lengths, then spp * max_depth extend cursors
         float4* d_hits = nullptr;     // closest-hit record per queue slot
-        std::vector<uint32_t> h_counts;
+        std::vector<uint32_t> h_counts, h_extra;
         hipStream_t stream = nullptr;
         hipEvent_t ev_done = nullptr;
         std::vector<hipEvent_t> ev_pool;
@@ -156,6 +163,7 @@ struct rt_renderer {
     // bounces rendered launch by launch (EXTEND + SHADE) before k_wf_finish follows the surviving rays to the end of their paths in
     // one launch per sample; >= max_depth = the reference's schedule (a launch pair per bounce). RT_WF_FINISH_DEPTH overrides.
     uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
+    uint32_t wf_samples_per_launch = RT_WF_SAMPLES_PER_LAUNCH_DEFAULT; // RT_WF_SAMPLES_PER_LAUNCH
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
@@ -256,8 +264,10 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&L.d_accum, m * 16));
             HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
             const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
-            HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + 1) * 4));
+            // spp * (max_depth + 1) queue lengths, spp * max_depth chunk cursors, spp "extra ray" counters of k_wf_finish
+            HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
             L.h_counts.resize(nc);
+            L.h_extra.resize(r->spp);
             HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
@@ -307,12 +317,17 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
                                                                             (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
-        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D) * 4, L.stream));
+        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp) * 4, L.stream));
         hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
         launches++;
     }
     // the lanes' chains are enqueued round-robin, bounce by bounce, so their kernels interleave on the device
-    for (uint32_t s = 0; s < r->spp; ++s) {
+    const uint32_t D0 = std::min(D, r->wf_finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
+    // samples one k_wf_finish launch renders per pixel: when it takes over from the camera ray on (D0 == 0) a lane whose path has ended
+    // generates the pixel's NEXT sample itself and goes on, for `chunk` samples, before it hands the RNG word back to memory
+    const uint32_t chunk = D0 == 0 && D > 0 ? std::max<uint32_t>(1u, std::min<uint32_t>(r->wf_samples_per_launch, r->spp)) : 1u;
+    for (uint32_t s = 0; s < r->spp; s += chunk) {
+        const uint32_t n_samples = std::min(chunk, r->spp - s);
         for (uint32_t k = 0; k < K; ++k) {
             auto& L = r->lanes[k];
             if (L.n_local == 0) continue;
@@ -321,7 +336,6 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                                L.d_counts + (size_t)s * (D + 1));
             launches++;
         }
-        const uint32_t D0 = std::min(D, r->wf_finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
         for (uint32_t d = 0; d < D0; ++d) {
             for (uint32_t k = 0; k < K; ++k) {
                 auto& L = r->lanes[k];
@@ -380,14 +394,14 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
                     HIPCHK(hipEventRecord(e0, ls));
                 }
-                // rays traced beyond bounce D0 go into counts[D0 + 1] (no queue of that depth exists: the host's sum over d < D takes it)
-                uint32_t* extra = counts + std::min(D0 + 1u, D);
+                // rays that are not a queue's length (every bounce beyond D0, every ray of the samples generated in-lane) are counted here
+                uint32_t* extra = cursors + (size_t)r->spp * D + s;
                 if (r->d_stats)
-                    hipLaunchKernelGGL(k_wf_finish<true>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, L.q[buf[k]], counts + D0, cursors + (size_t)s * D + D0,
-                                       L.d_rng, L.d_accum, extra, D0, D, r->rr_start, r->d_stats);
+                    hipLaunchKernelGGL(k_wf_finish<true>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,
+                                       cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start, r->d_stats);
                 else
-                    hipLaunchKernelGGL(k_wf_finish<false>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, L.q[buf[k]], counts + D0, cursors + (size_t)s * D + D0,
-                                       L.d_rng, L.d_accum, extra, D0, D, r->rr_start, (unsigned long long*)nullptr);
+                    hipLaunchKernelGGL(k_wf_finish<false>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,
+                                       cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start, (unsigned long long*)nullptr);
                 if (r->profile_kernels) {
                     HIPCHK(hipEventRecord(e1, ls));
                     ne[k] += 2;
@@ -559,8 +573,11 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
             for (auto& L : r->lanes) {
                 if (!L.n_local) continue;
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
-                for (uint32_t s = 0; s < r->spp; ++s)
-                    for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407
+                HIPCHK(hipMemcpy(L.h_extra.data(), L.d_counts + L.h_counts.size() + (size_t)r->spp * D, L.h_extra.size() * 4, hipMemcpyDeviceToHost));
+                for (uint32_t s = 0; s < r->spp; ++s) {
+                    for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407 (queue lengths)
+                    rays += L.h_extra[s];                                                        // rays k_wf_finish traced beyond a queue
+                }
             }
             local.rays = rays;
         }
@@ -783,6 +800,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) r->wf_finish_depth = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(1, std::atoi(e));
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';

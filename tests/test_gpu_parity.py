@@ -311,6 +311,38 @@ def test_native_frame_gather_equals_the_single_device_frame(gpu_scenes, oracle, 
     comm.close()
 
 
+@pytest.mark.parametrize("samples_per_launch", [1, 2, 3, 5, 64])
+def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypatch, samples_per_launch):
+    """RT_WF_SAMPLES_PER_LAUNCH (with RT_WF_FINISH_DEPTH = 0): the lane whose path has ended generates the same pixel's next camera ray
+    itself, for that many samples per launch, instead of waiting for the next k_wf_generate launch. 5 samples in chunks of 1, 2, 3,
+    5 and 64 (= all in one launch; 2 and 3 leave a shorter last chunk): frame, unorm8 image and ray count equal the oracle's
+    WavefrontRenderer, with Russian roulette and on an odd tile too."""
+    monkeypatch.setenv("RT_WF_FINISH_DEPTH", "0")
+    monkeypatch.setenv("RT_WF_SAMPLES_PER_LAUNCH", str(samples_per_launch))
+    for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 5), ("atrium", {"detail": 1}, (192, 108), 10, 5), ("cube", {}, (64, 40), 1, 5)):
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+        osc = oracle.OracleScene(sd)
+        r = WavefrontRenderer(gs, (w, h), depth, spp)
+        got = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch}")
+        again = r.render_frame(cam)
+        _assert_frames_equal(again.rgba_f32, again.rgba_u8, again.rays, f, b, rays, f"{name} second frame")
+        r.set_russian_roulette(2)
+        got_rr = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rr_start=2)
+        _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch} rr")
+        r.set_russian_roulette(0)
+        r.set_tile(1, 3, 8)
+        tile = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=1, world=3, strip_rows=8)
+        _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch} tile 1/3")
+        r.close()
+
+
 @pytest.mark.parametrize("finish_depth", [0, 1, 3, 7, 8, 99])
 def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, monkeypatch, finish_depth):
     """The wavefront renderer's schedule: the first RT_WF_FINISH_DEPTH bounces launch by launch (EXTEND + SHADE with global
