@@ -3,12 +3,14 @@ fed mutated files: truncations, bit flips and spliced garbage must be rejected w
 touch memory they do not own. (CPU only: GPU ASan is not available on this pool.)"""
 import io
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
 
 REPO = Path(__file__).resolve().parent.parent
 HOST = REPO / "sycl-ray-tracer_amd" / "host"
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 
 def test_loader_survives_mutated_files_under_asan_ubsan(tmp_path):
@@ -86,6 +88,37 @@ def test_loader_survives_mutated_files_under_asan_ubsan(tmp_path):
             p = tmp_path / f"g{gi}_{k}.glb"
             p.write_bytes(bytes(b))
             files.append(p)
+    # hand-crafted numbers that mutation never reaches: counts / offsets / strides whose products wrap around in size_t, negative
+    # and non-finite values, an image view whose offset + length wraps, and 100,000 nested arrays — under the sanitizers too
+    import struct
+    from test_host_cpp import _craft_glb
+    blob = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<9f", 0, 0, 1, 0, 0, 1, 0, 0, 1) + struct.pack("<6f", 0, 0, 1, 0, 0, 1) + struct.pack("<3H", 0, 1, 2) + b"\0\0"
+
+    def doc(**over):
+        d = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob)}],
+             "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 36},
+                             {"buffer": 0, "byteOffset": 72, "byteLength": 24}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+             "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+                           {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC2"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+             "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3}]}],
+             "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+        for k, v in over.items():
+            a, i, f = k.split("__")
+            d[a][int(i)][f] = v
+        return d
+
+    crafted = [doc(), doc(accessors__0__count=2 ** 61, bufferViews__0__byteStride=8), doc(accessors__3__count=1e300), doc(accessors__0__count=-3),
+               doc(bufferViews__1__byteOffset=-36), doc(accessors__2__byteOffset=2.0 ** 64), doc(bufferViews__0__byteStride=2 ** 63),
+               {**doc(), "scenes": [{"nodes": [-1]}]}, {**doc(), "scenes": [{"nodes": [1e30]}]}]
+    wrap = doc()
+    wrap["images"] = [{"bufferView": 4, "mimeType": "image/png"}]
+    wrap["bufferViews"].append({"buffer": 0, "byteOffset": 8, "byteLength": 2.0 ** 64 - 4})
+    crafted.append(wrap)
+    for ci, d in enumerate(crafted):
+        _craft_glb(tmp_path / f"crafted{ci}.glb", d, blob)
+        files.append(tmp_path / f"crafted{ci}.glb")
+    _craft_glb(tmp_path / "deep.glb", b"[" * 100000 + b"]" * 100000, b"")
+    files.append(tmp_path / "deep.glb")
     env = {"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1:allocator_may_return_null=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}
     p = subprocess.run([str(exe)] + [str(f) for f in files], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-4000:]
