@@ -4,7 +4,7 @@ import sys, time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/sycl-ray-tracer_amd')
 import numpy as np, torch
 from rtamd import scenes, abi
-from rtamd.renderer import Scene, Camera, MegakernelRenderer, WavefrontRenderer
+from rtamd.renderer import Scene, Camera, MegakernelRenderer, TileComm, WavefrontRenderer
 sd = scenes.atrium_scene(2); t0=time.time()
 free0 = None
 ref = {}
@@ -20,6 +20,17 @@ for it in range(40):
         else:
             ref[key] = fr.rays; globals().setdefault('refimg', {})[key] = fr.rgba_u8.copy()
         r.close()
+    if it % 5 == 0:  # the library's gather: communicator + two tiles created, used and destroyed
+        comm = TileComm((0, 0))
+        rs = [WavefrontRenderer(sc, (320, 180), 6, 2) for _ in range(2)]
+        for k, r in enumerate(rs): r.set_tile(k, 2, 8)
+        f, b, rays = comm.render_and_gather(rs, Camera.for_scene(sd, (320, 180)))
+        key = ("gather",)
+        if key in ref: assert ref[key] == rays and np.array_equal(refimg[key], b), key
+        else:
+            ref[key] = rays; globals().setdefault('refimg', {})[key] = b.copy()
+        for r in rs: r.close()
+        comm.close()
     sc.close()
     if it == 7: torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]  # after the runtime's one-time allocations
 torch.cuda.synchronize()
