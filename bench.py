@@ -280,7 +280,7 @@ def live_pmc(args, renderer, kernel):
     for counters in PMC_PASSES:
         with tempfile.TemporaryDirectory(prefix="rt_pmc_", dir="/tmp") as d:
             p = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=120)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if p.returncode != 0 or not files:
                 raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr[-300:]}")
