@@ -299,6 +299,9 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 // Two experiments kept behind flags, both bit-exact, both OFF (megakernel, atrium 1080p 16 spp, two runs each, default 7040 / 7039 Mrays/s):
 //   RT_SIGN_XOR=1    near / far plane words picked with v_ashrrev + xor / and instead of v_cmp + v_cndmask: 7047 / 7071 (noise)
 //   RT_LEAF_UNROLL=1 whole-leaf step unrolled over two register sets (no record copies, -100 static issue cycles): 6975 / 6944 (-1.2 %)
+#ifndef RT_STATS_LEAFWAIT
+#define RT_STATS_LEAFWAIT 0
+#endif
 #ifndef RT_SIGN_XOR
 #define RT_SIGN_XOR 0
 #endif
@@ -474,7 +477,11 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #define RT_LEAF_MIN 64u // with whole-leaf steps: leaf lanes that force a leaf step even against an inner majority
 #endif
     if (ni >= nl && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
+#if RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
+#else
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes));
+#endif
         if (inner) trav_inner(S, T, stack, top);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += nl;

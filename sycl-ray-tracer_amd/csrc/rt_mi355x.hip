@@ -18,6 +18,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
+#include "rt_kernel_ts.h"
 #include "scene_build.h"
 
 using namespace rt;
@@ -182,6 +183,10 @@ struct rt_renderer {
     // diagnostics (scripts/occupancy_probe.py): RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
     uint32_t mega_lds_pad = 0, mega_occ = RT_MEGA_WAVES;
+    // RT_MEGA_TS=1: k_megakernel_ts (traversal and shading decoupled inside every workgroup, rt_kernel_ts.h) instead of k_megakernel
+    bool mega_ts = false;
+    TsSlots ts_slots{};
+    uint32_t ts_blocks = 0;
 };
 
 namespace {
@@ -198,6 +203,7 @@ void free_tile_buffers(rt_renderer* r) {
         p = nullptr;
     };
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
+    fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
     for (auto& L : r->lanes) {
         fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
@@ -242,7 +248,17 @@ int alloc_tile_buffers(rt_renderer* r) {
     HIPCHK(hipMemsetAsync(r->d_u8, 0, n_pad * 4, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors
+        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors + error word
+        if (r->mega_ts) {
+            const uint32_t tiles = (uint32_t)((r->width + 7) / 8) * (uint32_t)((r->tile.local_rows + 7) / 8);
+            r->ts_blocks = std::max<uint32_t>(1u, std::min<uint32_t>((tiles + 7u) / 8u, (uint32_t)r->n_cus * 3u)); // three workgroups per CU
+            const size_t ns = (size_t)r->ts_blocks * RT_TS_SLOTS;
+            HIPCHK(hipMalloc((void**)&r->ts_slots.org_px, ns * 16));
+            HIPCHK(hipMalloc((void**)&r->ts_slots.state, ns * 16));
+            HIPCHK(hipMalloc((void**)&r->ts_slots.misc, ns * 8));
+            HIPCHK(hipMalloc((void**)&r->ts_slots.color_s, ns * 16));
+            HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
+        }
     } else {
         uint32_t K = 2;
         if (const char* e = std::getenv("RT_WF_STREAMS")) K = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
@@ -458,6 +474,15 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipEventRecord(e0, st));
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
+        } else if (r->mega_ts) {
+            if (r->d_stats) {
+                HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_megakernel_ts<true>, dim3(r->ts_blocks), dim3(kTsBlock), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode,
+                                   r->rr_start, d_f32, d_u8, r->d_ray_counter, r->ts_slots, r->d_stats);
+            } else {
+                hipLaunchKernelGGL(k_megakernel_ts<false>, dim3(r->ts_blocks), dim3(kTsBlock), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode,
+                                   r->rr_start, d_f32, d_u8, r->d_ray_counter, r->ts_slots, (unsigned long long*)nullptr);
+            }
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
@@ -564,9 +589,10 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
     }
     if (r->n_local) {
         if (r->kind == RT_RENDERER_MEGAKERNEL) {
-            unsigned long long rays = 0;
-            HIPCHK(hipMemcpy(&rays, r->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
-            local.rays = rays;
+            unsigned long long ctr[8] = {0};
+            HIPCHK(hipMemcpy(ctr, r->d_ray_counter, sizeof(ctr), hipMemcpyDeviceToHost));
+            local.rays = ctr[0];
+            if (ctr[5]) return fail(RT_ERR_HIP, "k_megakernel_ts: a queue entry did not become valid (internal error word set)");
         } else {
             uint64_t rays = 0;
             const uint32_t D = r->max_depth;
@@ -592,7 +618,12 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                      rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
                      h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
                      rays ? (double)h[1] / rays : 0.0, rays ? (double)h[7] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
-        if (h[10])
+        if (r->mega_ts && h[8])
+            std::fprintf(stderr, "[rt stats ts] T: %llu rounds of %d steps (%.1f lanes holding a slot), %llu idle polls, %llu refills (%.1f slots each), "
+                         "%.0f cycles per round incl. idle, %.0f of them in the steps | S: %llu rounds (%.1f lanes), %.0f cycles per round\n",
+                         h[8], RT_MEGA_UNROLL, (double)h[12] / h[8], h[9], h[10], h[10] ? (double)h[11] / h[10] : 0.0, (double)h[13] / h[8], (double)h[6] / h[8],
+                         h[4], h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[14] / h[4] : 0.0);
+        if (!r->mega_ts && h[10])
             std::fprintf(stderr, "[rt stats] waves %llu | cycles per wave: mean %.0f, max %llu | traversal %.1f%%, shading %.1f%% of wave time | "
                          "%.0f cycles per traversal step, %.0f per shade round\n",
                          h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
@@ -784,6 +815,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
+    if (const char* e = std::getenv("RT_MEGA_TS")) r->mega_ts = e[0] == '1' && kind == RT_RENDERER_MEGAKERNEL;
     if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);

@@ -311,6 +311,38 @@ def test_native_frame_gather_equals_the_single_device_frame(gpu_scenes, oracle, 
     comm.close()
 
 
+def test_megakernel_with_decoupled_shading_waves_keeps_the_frame(gpu_scenes, oracle, monkeypatch):
+    """RT_MEGA_TS=1: k_megakernel_ts — seven traversal waves and one shading wave per workgroup exchange pixel slots through two LDS
+    queues (rt_kernel_ts.h). A pixel's rays are still traced and shaded one after the other, by different lanes: frame, unorm8 image
+    and ray count must equal the oracle's MegakernelRenderer — tiny frames (fewer pixels than one workgroup has slots), frames that
+    are not a multiple of the 8x8 tiles, odd tile splits, Russian roulette, max_depth 1, and the same renderer twice."""
+    monkeypatch.setenv("RT_MEGA_TS", "1")
+    cases = (("cube", {}, (1, 1), 5, 2), ("cube", {}, (37, 21), 1, 3), ("cornell", {}, (96, 64), 8, 4), ("atrium", {"detail": 1}, (256, 144), 10, 3),
+             ("cornell", {}, (333, 187), 6, 2))
+    for name, kw, (w, h), depth, spp in cases:
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+        osc = oracle.OracleScene(sd)
+        r = MegakernelRenderer(gs, (w, h), depth, spp)
+        for rep in range(2):
+            got = r.render_frame(cam)
+            f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"))
+            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {w}x{h} ts rep {rep}")
+        r.set_russian_roulette(2)
+        got = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"), rr_start=2)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} ts rr")
+        r.set_russian_roulette(0)
+        if h >= 24:
+            r.set_tile(1, 3, 8)
+            tile = r.render_frame(cam)
+            f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"), rank=1, world=3, strip_rows=8)
+            _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} ts tile 1/3")
+        r.close()
+
+
 @pytest.mark.parametrize("samples_per_launch", [1, 2, 3, 5, 64])
 def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypatch, samples_per_launch):
     """RT_WF_SAMPLES_PER_LAUNCH (with RT_WF_FINISH_DEPTH = 0): the lane whose path has ended generates the same pixel's next camera ray
