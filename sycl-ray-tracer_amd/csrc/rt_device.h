@@ -156,6 +156,16 @@ RT_DEV void tri_test(const TriRec* __restrict__ tr, f3 o, f3 d, Hit& best) {
 // one loop) was 27 %. The box test is a padded-box cull: it uses fma and an approximate reciprocal on
 // purpose (never visible in results).
 constexpr int32_t kTravDone = (int32_t)0x80000000;
+// RT_POSTPONE=1 (experiment): a lane that reaches a leaf while its wave keeps taking inner steps does not wait for the leaf vote:
+// it sets the leaf aside (one per lane), pops its stack and goes on with inner nodes; the leaf is tested at the wave's next leaf
+// step. The closest hit does not depend on the order of the tests (ties go to the lower triangle index), so results are unchanged;
+// what it costs is culling (nodes visited with a stale best.t) and a few instructions per step.
+#ifndef RT_POSTPONE
+#define RT_POSTPONE 0
+#endif
+#ifndef RT_PP_VOTE
+#define RT_PP_VOTE 0
+#endif
 
 struct Trav {
     f3 o, d;              // ray (d unnormalised, as stored)
@@ -164,6 +174,10 @@ struct Trav {
     Hit best;
     int32_t cur;
     uint32_t sp; // LDS byte address of the lane's next free stack entry (TravStack::base = empty); beyond the LDS part it keeps counting
+#if RT_POSTPONE
+    int32_t pend = kTravDone; // a postponed leaf (same code as `cur`) or kTravDone: none. Invariant: cur == kTravDone => pend == kTravDone
+                              // (a pop from an empty stack hands the postponed leaf back to `cur`)
+#endif
 };
 
 struct TravStack;
@@ -183,6 +197,9 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
     T.ox = -o.x * T.ix, T.oy = -o.y * T.iy, T.oz = -o.z * T.iz;
     T.cur = 0; // root
     T.sp = stack_base(st); // empty stack
+#if RT_POSTPONE
+    T.pend = kTravDone;
+#endif
 }
 
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (entry-major, lane-minor:
@@ -215,7 +232,11 @@ RT_DEV void trav_pop_lds(Trav& T, const TravStack& st) { // caller: stack_shallo
         T.sp -= st.pitch;
         T.cur = *lds_at(T.sp);
     } else {
+#if RT_POSTPONE
+        T.cur = T.pend, T.pend = kTravDone;
+#else
         T.cur = kTravDone;
+#endif
     }
 }
 RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) { // any depth
@@ -230,7 +251,11 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
         const uint32_t e = (T.sp - st.base) / st.pitch;
         T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
     } else {
+#if RT_POSTPONE
+        T.cur = T.pend, T.pend = kTravDone;
+#else
         T.cur = kTravDone;
+#endif
     }
 }
 
@@ -385,17 +410,26 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 #endif
     // with fewer than five comparators the hits are no longer a sorted prefix of (k1, k2, k3): each is tested on its own below
 #undef RT_CE
+#if RT_POSTPONE
+    // the nearest hit child is a leaf and nothing is set aside yet: set it aside and go on with the next nearest entry
+    const bool hit0 = k0 < inf;
+    const bool aside = hit0 && (uint32_t)c0 > 0x80000000u && T.pend == kTravDone;
+    if (aside) T.pend = c0;
+    const bool descend = hit0 && !aside;
+#else
+    const bool descend = k0 < inf;
+#endif
     if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
         if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
         if (k2 < inf) stk_push_lds(stack, T, c2);
         if (k1 < inf) stk_push_lds(stack, T, c1);
-        if (k0 < inf) T.cur = c0;
+        if (descend) T.cur = c0;
         else trav_pop_lds(T, stack);
     } else {
         if (k3 < inf) stk_push(stack, T, c3);
         if (k2 < inf) stk_push(stack, T, c2);
         if (k1 < inf) stk_push(stack, T, c1);
-        if (k0 < inf) T.cur = c0;
+        if (descend) T.cur = c0;
         else trav_pop(T, stack);
     }
 }
@@ -407,7 +441,12 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 // megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
 template <bool BATCH>
 RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
+#if RT_POSTPONE
+    const bool from_pend = T.pend != kTravDone; // the postponed leaf first: it is the older (usually nearer) one
+    const uint32_t code = (uint32_t)~(from_pend ? T.pend : T.cur);
+#else
     const uint32_t code = (uint32_t)~T.cur;
+#endif
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
 #if RT_LEAF_UNROLL
@@ -452,12 +491,33 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         }
         if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
 #endif
+#if RT_POSTPONE
+        // the lane's own leaf is done: pop. The postponed one is done: if the lane also sits at a leaf, that one is set aside now
+        bool pop = true;
+        if (from_pend) {
+            pop = (uint32_t)T.cur > 0x80000000u;
+            T.pend = pop ? T.cur : kTravDone;
+        }
+        if (lanes(pop && !stack_shallow(stack, T, 0u)) == 0ull) {
+            if (pop) trav_pop_lds(T, stack);
+        } else if (pop) {
+            trav_pop(T, stack);
+        }
+#else
         if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
         else trav_pop(T, stack);
+#endif
     } else {
         tri_test(S.tris + first, T.o, T.d, T.best);
+#if RT_POSTPONE
+        const int32_t next = rem ? ~(int32_t)(((first + 1u) << 2) | (rem - 1u)) : kTravDone;
+        if (from_pend) T.pend = next;
+        else if (rem) T.cur = next;
+        else trav_pop(T, stack);
+#else
         if (rem) T.cur = ~(int32_t)(((first + 1u) << 2) | (rem - 1u));
         else trav_pop(T, stack);
+#endif
     }
 }
 
@@ -471,8 +531,18 @@ struct WaveStats {
 template <bool STATS = false, bool LEAF_BATCH = false>
 RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, WaveStats* ws = nullptr) {
     const bool inner = T.cur >= 0;
+#if RT_POSTPONE
+    const bool blocked = (uint32_t)T.cur > 0x80000000u; // at a leaf (negative, not kTravDone)
+    const bool leaf = blocked || T.pend != kTravDone;
+#if RT_PP_VOTE // leaf steps only when the lanes that cannot take an inner step outnumber those that can
+    const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(blocked));
+#else
+    const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
+#endif
+#else
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
+#endif
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 64u // with whole-leaf steps: leaf lanes that force a leaf step even against an inner majority
 #endif
@@ -484,7 +554,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #endif
         if (inner) trav_inner(S, T, stack, top);
     } else {
-        if (STATS) ws->leaf_steps++, ws->leaf_lanes += nl;
+        if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(__ballot(leaf));
         if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
     }
     return ni + nl;

@@ -621,13 +621,55 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 // word it holds in a register, exactly what k_wf_generate would do after reading that word back from memory — and goes on, for
 // n_samples samples, before it stores the word and takes the next queue slot. This removes the per-sample launch boundary and its
 // drain tail as well (the queue then feeds only the chunk's first sample).
-template <bool STATS>
+// n_samples > 1 with a FinishRequeue (REQ, the streaming schedule): breadth first instead of depth first. The lane whose path has ended
+// does not keep the pixel: it appends (pixel, samples left, RNG word) to a DEVICE-WIDE dynamic queue; any lane that is idle once the
+// sample-0 queue is used up takes the pixel from there and generates its next camera ray with the word it finds in the entry (what
+// k_wf_generate does after reading the word back from rng_buf). All pixels thus advance through their samples together and a launch
+// of C samples ends with single paths, not with pixel-chunks: one drain tail per C samples, and every idle lane of the chip can take
+// any waiting pixel.
+// The queue is an array of P = pixels x (C - 1) entries — exactly the number of hand-overs of a launch — used once, front to back.
+//   producers: a wave stages the entries of its ended paths in LDS and appends >= 32 at a time (or whatever it has when some lane of
+//              it starves): one ticket atomic on `tail`, then one 8-byte store per entry.
+//   consumers: idle lanes take POSITIONS with one atomic add on `head` per wave (>= 16 at a time), whether or not the entries exist
+//              yet, and then poll their position once per loop iteration — the load is issued in one iteration and looked at in the
+//              next, so nobody waits for it, and a wave whose other lanes have rays keeps traversing. A position >= P will never be
+//              written: the lane retires. A wave leaves when all its lanes have retired.
+//   No wave ever waits for another inside a loop of its own, so there is nothing to deadlock; every position < P is written (every
+//   pixel ends each of its samples) and read exactly once.
+// Hand-over between CUs (MI355X: private L1 per CU, private L2 per XCD, neither refreshed by another CU's stores): every byte that
+// changes hands inside the launch — the accumulator and the queue entry {pixel | (samples left - 1) << 24, RNG word} — is written with
+// write-through (`sc1`) stores and read with `sc1` loads, never through a plain load. An entry is ONE 8-byte store and carries its own
+// validity (all ones until written); the accumulator (one 16-byte store) is written when the path ends, the entry after the wave's
+// ticket atomic has returned, and waiting for that return (s_waitcnt vmcnt(0), in-order) retires the accumulator store first.
+struct FinishRequeue {
+    unsigned long long* entries; // P entries, all ones before the launch
+    uint32_t* ctl;               // one 64-byte line each, zero before the launch: [0] tail, [32] head
+    uint32_t capacity;           // >= P (host-sized)
+};
+#ifndef RT_RQ_STAGE
+#define RT_RQ_STAGE 96u
+#endif
+#ifndef RT_RQ_FLUSH
+#define RT_RQ_FLUSH 32u
+#endif
+#ifndef RT_RQ_CLAIM
+#define RT_RQ_CLAIM 16u
+#endif
+#ifndef RT_RQ_STALE
+#define RT_RQ_STALE 4u // shading rounds an entry may wait in a busy wave's stage
+#endif
+constexpr uint32_t kRqEmpty = 0xFFFFFFFFu, kRqStage = RT_RQ_STAGE, kRqFlush = RT_RQ_FLUSH, kRqClaim = RT_RQ_CLAIM;
+static_assert(kRqFlush + 64u <= kRqStage, "a whole wave of new entries must fit behind an unflushed stage");
+RT_DEV unsigned long long rq_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RT_DEV void rq_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool STATS, bool REQ>
 __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
                                                                     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
                                                                     uint32_t* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
                                                                     uint32_t n_samples, uint32_t rr_start,
-                                                                    unsigned long long* __restrict__ stats_out) {
+                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq) {
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
@@ -635,6 +677,18 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
     RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
+    __shared__ unsigned long long rq_stage_mem[REQ ? kWavesPerBlock * kRqStage : 1u];
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+    lds_u64_t* stage = (lds_u64_t*)rq_stage_mem + (threadIdx.x >> 6) * kRqStage; // REQ: this wave's staged entries
+    uint32_t staged = 0, stale = 0;                                                // wave-uniform: entries staged, shading rounds since they wait
+    const uint32_t total_entries = REQ ? n * (n_samples - 1u) : 0u;                // P
+    const auto accum_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)accum, 0, (int)(n * 16u), 0x00020000); // REQ: 16-byte sc1 accesses
+    bool chunk_dq = false; // REQ: the wave's current chunk is a range of POSITIONS of the dynamic queue
+    bool drained = false;  // REQ: the dynamic queue has no position left (wave-uniform)
+    // REQ: this lane holds a position of the dynamic queue and polls it. A waiting lane has no pixel, so its position lives in `id` and
+    // the two words of the polled entry land in `samples_left` and `rng` — where they belong once the entry is there — instead of in
+    // registers of their own (three VGPRs that would be live across the traversal loop of a kernel that already spills).
+    bool waiting = false;
     Trav T;
     T.cur = kTravDone;
     bool live = false;
@@ -644,45 +698,104 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     bool first_counted = false; // the current path's first ray is a queue entry (counted by the host as the queue's length)
     uint32_t chunk_pos = wave_id * kExtendChunk; // first chunk static, later ones from the cursor (as EXTEND)
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
-    bool exhausted = chunk_pos >= n;
-    if (exhausted) return;
+    bool exhausted = chunk_pos >= n; // the sample-0 queue has no chunk left for this wave
+    if (exhausted) {
+        if (!REQ) return;
+        chunk_pos = chunk_end = 0;
+    }
+    auto flush = [&]() { // REQ: append the wave's staged entries to the dynamic queue
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(fq.ctl + 0, staged);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every accumulator store this wave has made is at the L2 before an entry names its pixel
+        for (uint32_t i = lane; i < staged; i += 64u)
+            if (t + i < fq.capacity) rq_store64(fq.entries + t + i, stage[i]);
+        staged = 0;
+    };
     for (;;) {
-        if (!exhausted) {
-            const unsigned long long idle_m = __ballot(!live);
+        if (REQ && waiting && samples_left != kRqEmpty) { // last iteration's poll found the entry: k_wf_generate's body with the word in it
+            const uint32_t e = samples_left;
+            id = e & 0xFFFFFFu, samples_left = (e >> 24) + 1u;
+            const CameraDev cam = *camp;
+            const int x = (int)(id % (uint32_t)cam.width), ly = (int)(id / (uint32_t)cam.width);
+            r = camera_ray(cam, x, tile_global_row(tile, ly), rng);
+            depth = 0, first_counted = false;
+            trav_begin(T, r.org, ray_dir(r), stack);
+            live = true, waiting = false;
+        }
+        if (!(REQ ? drained : exhausted)) {
+            const unsigned long long idle_m = __ballot(!live && !waiting);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
             if (cnt >= RT_MEGA_REFILL) {
                 if (chunk_pos == chunk_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, kExtendChunk);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * kExtendChunk;
-                    if (base >= n) exhausted = true;
-                    chunk_pos = base;
-                    chunk_end = base + kExtendChunk < n ? base + kExtendChunk : n;
+                    if (!exhausted) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(cursor, kExtendChunk);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * kExtendChunk;
+                        if (base >= n) {
+                            exhausted = true;
+                        } else {
+                            chunk_pos = base;
+                            chunk_end = base + kExtendChunk < n ? base + kExtendChunk : n;
+                        }
+                    }
+                    if (REQ && exhausted) { // positions of the dynamic queue, whether their entries exist yet or not
+                        const uint32_t w = cnt > kRqClaim ? cnt : kRqClaim;
+                        uint32_t h = 0;
+                        if (lane == 0) h = atomicAdd(fq.ctl + 32, w);
+                        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+                        if (h >= total_entries) {
+                            drained = true; // every hand-over of this launch already has its taker
+                        } else {
+                            chunk_pos = h;
+                            chunk_end = h + w < total_entries ? h + w : total_entries;
+                            chunk_dq = true;
+                        }
+                    }
                 }
-                if (!exhausted) {
+                if (chunk_pos != chunk_end) {
                     const uint32_t avail = chunk_end - chunk_pos;
                     const uint32_t take = cnt < avail ? cnt : avail;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                    if (!live && rank < take) {
-                        id = queue_load(qin, chunk_pos + rank, r);
-                        rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
-                        depth = first_depth;
-                        samples_left = n_samples, first_counted = true;
-                        trav_begin(T, r.org, ray_dir(r), stack);
-                        live = true;
+                    if (!live && !waiting && rank < take) {
+                        if (REQ && chunk_dq) {
+                            id = chunk_pos + rank; // the lane's position
+                            waiting = true;
+                        } else {
+                            id = queue_load(qin, chunk_pos + rank, r);
+                            rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
+                            depth = first_depth;
+                            samples_left = n_samples, first_counted = true;
+                            trav_begin(T, r.org, ray_dir(r), stack);
+                            live = true;
+                        }
                     }
                     chunk_pos += take;
                 }
             }
         }
+        const unsigned long long wait_m = REQ ? __ballot(waiting) : 0ull;
+        if (REQ && waiting) { // looked at in the next iteration
+            const unsigned long long e64 = rq_load64(fq.entries + id);
+            samples_left = (uint32_t)e64, rng = (uint32_t)(e64 >> 32);
+        }
         const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
         if (n_live == 0) {
-            if (exhausted) break;
+            if (!REQ) {
+                if (exhausted) break;
+                continue;
+            }
+            if (staged) flush(); // nothing to trace: hand over what this wave still holds
+            if (wait_m != 0ull) {
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            if (drained) break;
             continue;
         }
         for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
-            const bool waiting = live && T.cur == kTravDone;
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
+            const bool done_trav = live && T.cur == kTravDone;
+            if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
@@ -690,6 +803,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
 #if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
+        bool requeue = false;
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
             if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum
             f3 res;
@@ -697,15 +811,27 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             depth++;
             bool ends = done;
             if (done) {
-                float4 acc = accum[id];
+                float4 acc;
+                if (REQ) { // the pixel's previous sample may have been added by another CU: one 16-byte sc1 load, served by the L2
+                    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(accum_rsrc, (int)(id * 16u), 0, 16 /* sc1 */);
+                    acc = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+                } else {
+                    acc = accum[id];
+                }
                 acc.x = acc.x + clamp01(res.x), acc.y = acc.y + clamp01(res.y), acc.z = acc.z + clamp01(res.z);
-                accum[id] = acc;
+                if (REQ) { // write-through (sc1): the pixel's next sample may be added by another CU
+                    u32x4 a;
+                    a.x = __float_as_uint(acc.x), a.y = __float_as_uint(acc.y), a.z = __float_as_uint(acc.z), a.w = __float_as_uint(acc.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(a, accum_rsrc, (int)(id * 16u), 0, 16 /* sc1 */);
+                } else {
+                    accum[id] = acc;
+                }
             } else if (depth == max_depth) {
                 ends = true; // survivors of the last depth contribute (0,0,0) (:279-280)
             } else if (rr_start && depth >= rr_start) {
                 ends = !roulette(rng, r);
             }
-            if (ends && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
+            if (!REQ && ends && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
                 const CameraDev cam = *camp;
                 const int x = (int)(id % (uint32_t)cam.width), ly = (int)(id / (uint32_t)cam.width);
                 r = camera_ray(cam, x, tile_global_row(tile, ly), rng);
@@ -713,11 +839,25 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 ends = false;
             }
             if (ends) {
-                rng_buf[id] = rng; // ScopedRng store
                 live = false;
+                if (REQ) requeue = samples_left > 1u;
+                if (!requeue) rng_buf[id] = rng; // ScopedRng store (the next launch reads it; inside this launch the word travels in the entry)
             } else {
                 trav_begin(T, r.org, ray_dir(r), stack);
             }
+        }
+        if (REQ) {
+            const unsigned long long rq_m = __ballot(requeue);
+            const uint32_t n_rq = (uint32_t)__popcll(rq_m);
+            if (n_rq) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rq_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rq_m, 0u));
+                if (requeue) stage[staged + rank] = (unsigned long long)(id | ((samples_left - 2u) << 24)) | ((unsigned long long)rng << 32);
+                staged += n_rq;
+            }
+            // append when there is enough to amortise the ticket — or at once when a lane of this wave starves (work is scarce: pass it on),
+            // and in any case after a few rounds, so that no pixel waits long in a busy wave's stage
+            stale = staged ? stale + 1u : 0u;
+            if (staged >= kRqFlush || (staged && (wait_m != 0ull || stale >= RT_RQ_STALE))) flush(), stale = 0;
         }
 #if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(2);

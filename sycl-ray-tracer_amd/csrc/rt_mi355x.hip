@@ -31,13 +31,21 @@ using namespace rt;
 #ifndef RT_WF_FINISH_DEPTH_DEFAULT
 #define RT_WF_FINISH_DEPTH_DEFAULT 0u
 #endif
-// Samples k_wf_finish renders per pixel and launch (streaming: the lane generates the pixel's next camera ray itself). Measured, atrium
-// 1080p 16 spp: 1 / 2 / 4 / 8 / 16 samples per launch = 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s (megakernel 6965); config 5's tile
-// 40.3 / - / 42.8 / 43.8 / 43.0 ms. Fewer launch boundaries, but a lane then holds its pixel for the whole chunk and the launch ends
-// with its slowest pixel-chunk: the tail grows as fast as the boundaries vanish. Default 1: one launch per sample.
+// Samples k_wf_finish renders per pixel and launch (the streaming schedule, rt_kernels.h). Two forms, both bit-exact for every value:
+//  - depth first (RT_WF_REQUEUE=0): the lane keeps its pixel and generates the next camera ray itself. Atrium 1080p 16 spp, 1 / 2 / 4 /
+//    8 / 16 samples per launch: 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s; config 5's tile 40.3 / - / 42.8 / 43.8 / 43.0 ms: fewer launch
+//    boundaries, but the launch ends with its slowest pixel-CHUNK: the tail grows as fast as the boundaries vanish.
+//  - breadth first (default form): the pixel goes through a device-wide dynamic queue to whichever lane is idle, so a launch ends with
+//    single paths. Depth 10, 16 spp, by frame size, Mrays/s at 1 / 4 / 16 samples per launch: 960x540 4253 / 4244 / 4368; 1920x540
+//    5081 / 5830 / 5869; 1920x1080 6334 / 6179 / 5946; 2560x1440 6825 / 6230 / 6025; 3840x2160 7032 / 6248 / 5843; config 5's tile
+//    (1.04 M pixels, depth 16) 40.0 / 33.3 / 32.8 ms against the megakernel's 30.6. The queue costs ~12 % more VALU instructions and
+//    ~30 % more L2 misses (a wave's pixels are no longer neighbours after their first sample) and levels off at ~6.0 Grays/s, while
+//    a launch per sample climbs with the frame as its tails amortise: streaming wins below ~1.5 M pixels per GPU and loses above.
+// Default 0 = choose by the tile: 16 samples per launch below kStreamingPixels, otherwise one launch per sample.
 #ifndef RT_WF_SAMPLES_PER_LAUNCH_DEFAULT
-#define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 1u
+#define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 0u
 #endif
+constexpr uint32_t kStreamingPixels = 1500000u, kStreamingSamples = 16u;
 
 namespace {
 
@@ -140,6 +148,11 @@ struct rt_renderer {
         float4* d_accum = nullptr;
         uint32_t* d_counts = nullptr; // spp * (max_depth + 1) queue lengths, then spp * max_depth extend cursors
         float4* d_hits = nullptr;     // closest-hit record per queue slot
+        // the streaming schedule's dynamic queue (k_wf_finish<.., true>): entries (all ones before every launch) and control words
+        // (tail, head: one 64-byte line each, zeroed before every launch)
+        unsigned long long* d_rq_entries = nullptr;
+        uint32_t* d_rq_ctl = nullptr;
+        uint32_t rq_capacity = 0;
         std::vector<uint32_t> h_counts, h_extra;
         hipStream_t stream = nullptr;
         hipEvent_t ev_done = nullptr;
@@ -165,6 +178,7 @@ struct rt_renderer {
     // one launch per sample; >= max_depth = the reference's schedule (a launch pair per bounce). RT_WF_FINISH_DEPTH overrides.
     uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
     uint32_t wf_samples_per_launch = RT_WF_SAMPLES_PER_LAUNCH_DEFAULT; // RT_WF_SAMPLES_PER_LAUNCH
+    bool wf_requeue = true; // with several samples per launch: breadth first through a device-wide dynamic queue (RT_WF_REQUEUE=0: the lane keeps its pixel)
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
@@ -205,7 +219,7 @@ void free_tile_buffers(rt_renderer* r) {
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
     fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
     for (auto& L : r->lanes) {
-        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits);
+        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
@@ -227,6 +241,22 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
     for (int32_t y = 0; y < height; ++y)
         if (((uint32_t)y / t.strip_rows) % t.world == t.rank) rows++;
     return rows;
+}
+
+// samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
+// camera ray on; bounded so that a launch's ray counter (32 bits), the entry's 8-bit sample field and the dynamic queue (<= 1 GiB per
+// stream lane) cannot overflow
+uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
+    const uint32_t want = r->wf_samples_per_launch ? r->wf_samples_per_launch
+                          : (r->wf_requeue && (uint64_t)r->n_local < kStreamingPixels ? kStreamingSamples : 1u);
+    if (r->wf_finish_depth != 0 || r->max_depth == 0 || want <= 1 || n_local == 0) return 1u;
+    uint64_t c = std::min<uint64_t>(std::min<uint32_t>(want, r->spp), 256u);
+    c = std::min<uint64_t>(c, std::max<uint64_t>(1, 0xFFFFFFFFull / ((uint64_t)n_local * r->max_depth)));
+    if (r->wf_requeue) {
+        c = std::min<uint64_t>(c, std::max<uint64_t>(1, ((1ull << 30) / 8) / n_local + 1));
+        if (n_local > (1u << 24)) c = 1; // the entry's pixel field has 24 bits
+    }
+    return (uint32_t)std::max<uint64_t>(1, c);
 }
 
 int alloc_tile_buffers(rt_renderer* r) {
@@ -284,6 +314,12 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
             L.h_counts.resize(nc);
             L.h_extra.resize(r->spp);
+            const uint32_t chunk = wf_chunk(r, L.n_local);
+            if (chunk > 1 && r->wf_requeue) { // every pixel is appended once per sample of a launch but its first
+                L.rq_capacity = L.n_local * (chunk - 1u);
+                HIPCHK(hipMalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
+                HIPCHK(hipMalloc((void**)&L.d_rq_ctl, 80 * 4));
+            }
             HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
@@ -333,7 +369,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
                                                                             (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
-        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp) * 4, L.stream));
+        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, L.stream));
         hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
         launches++;
     }
@@ -341,7 +377,9 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     const uint32_t D0 = std::min(D, r->wf_finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
     // samples one k_wf_finish launch renders per pixel: when it takes over from the camera ray on (D0 == 0) a lane whose path has ended
     // generates the pixel's NEXT sample itself and goes on, for `chunk` samples, before it hands the RNG word back to memory
-    const uint32_t chunk = D0 == 0 && D > 0 ? std::max<uint32_t>(1u, std::min<uint32_t>(r->wf_samples_per_launch, r->spp)) : 1u;
+    uint32_t chunk = r->spp;
+    for (uint32_t k = 0; k < K; ++k)
+        if (r->lanes[k].n_local) chunk = std::min(chunk, wf_chunk(r, r->lanes[k].n_local));
     for (uint32_t s = 0; s < r->spp; s += chunk) {
         const uint32_t n_samples = std::min(chunk, r->spp - s);
         for (uint32_t k = 0; k < K; ++k) {
@@ -412,12 +450,21 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 }
                 // rays that are not a queue's length (every bounce beyond D0, every ray of the samples generated in-lane) are counted here
                 uint32_t* extra = cursors + (size_t)r->spp * D + s;
-                if (r->d_stats)
-                    hipLaunchKernelGGL(k_wf_finish<true>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,
-                                       cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start, r->d_stats);
-                else
-                    hipLaunchKernelGGL(k_wf_finish<false>, dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,
-                                       cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start, (unsigned long long*)nullptr);
+                const bool req = n_samples > 1 && L.d_rq_entries != nullptr;
+                FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, L.rq_capacity};
+                if (req) { // the launch's dynamic queue: all entries invalid, counters zero
+                    HIPCHK(hipMemsetAsync(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls));
+                    HIPCHK(hipMemsetAsync(L.d_rq_ctl, 0, 80 * 4, ls));
+                }
+#define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
+    hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
+                       cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
+                       ST ? r->d_stats : (unsigned long long*)nullptr, fq)
+                if (r->d_stats && req) RT_FINISH_LAUNCH(true, true);
+                else if (r->d_stats) RT_FINISH_LAUNCH(true, false);
+                else if (req) RT_FINISH_LAUNCH(false, true);
+                else RT_FINISH_LAUNCH(false, false);
+#undef RT_FINISH_LAUNCH
                 if (r->profile_kernels) {
                     HIPCHK(hipEventRecord(e1, ls));
                     ne[k] += 2;
@@ -832,7 +879,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) r->wf_finish_depth = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(0, std::atoi(e)); // 0 = by tile size
+        if (const char* e = std::getenv("RT_WF_REQUEUE")) r->wf_requeue = e[0] != '0';
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';

@@ -343,13 +343,16 @@ def test_megakernel_with_decoupled_shading_waves_keeps_the_frame(gpu_scenes, ora
         r.close()
 
 
+@pytest.mark.parametrize("requeue", [1, 0])
 @pytest.mark.parametrize("samples_per_launch", [1, 2, 3, 5, 64])
-def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypatch, samples_per_launch):
-    """RT_WF_SAMPLES_PER_LAUNCH (with RT_WF_FINISH_DEPTH = 0): the lane whose path has ended generates the same pixel's next camera ray
-    itself, for that many samples per launch, instead of waiting for the next k_wf_generate launch. 5 samples in chunks of 1, 2, 3,
-    5 and 64 (= all in one launch; 2 and 3 leave a shorter last chunk): frame, unorm8 image and ray count equal the oracle's
-    WavefrontRenderer, with Russian roulette and on an odd tile too."""
+def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypatch, samples_per_launch, requeue):
+    """RT_WF_SAMPLES_PER_LAUNCH (with RT_WF_FINISH_DEPTH = 0): k_wf_finish renders that many samples of every pixel per launch instead
+    of one. requeue = 1 (default): the lane whose path has ended hands the pixel, with its RNG word, to a device-wide dynamic queue and
+    any idle lane generates its next camera ray (breadth first); requeue = 0: the lane keeps the pixel and generates the next camera
+    ray itself (depth first). 5 samples in chunks of 1, 2, 3, 5 and 64 (= all in one launch; 2 and 3 leave a shorter last chunk):
+    frame, unorm8 image and ray count equal the oracle's WavefrontRenderer, with Russian roulette and on an odd tile too."""
     monkeypatch.setenv("RT_WF_FINISH_DEPTH", "0")
+    monkeypatch.setenv("RT_WF_REQUEUE", str(requeue))
     monkeypatch.setenv("RT_WF_SAMPLES_PER_LAUNCH", str(samples_per_launch))
     for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 5), ("atrium", {"detail": 1}, (192, 108), 10, 5), ("cube", {}, (64, 40), 1, 5)):
         gs = gpu_scenes(name, **kw)
