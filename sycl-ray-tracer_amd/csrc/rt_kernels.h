@@ -655,6 +655,9 @@ struct FinishRequeue {
 #ifndef RT_RQ_CLAIM
 #define RT_RQ_CLAIM 16u
 #endif
+#ifndef RT_RQ_IDLE_SLEEP
+#define RT_RQ_IDLE_SLEEP 8
+#endif
 #ifndef RT_RQ_STALE
 #define RT_RQ_STALE 4u // shading rounds an entry may wait in a busy wave's stage
 #endif
@@ -669,7 +672,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
                                                                     uint32_t* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
                                                                     uint32_t n_samples, uint32_t rr_start,
-                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq) {
+                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots) {
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
@@ -696,8 +699,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     uint32_t id = 0, rng = 0, depth = 0, rays = 0;
     uint32_t samples_left = 0;  // samples of this lane's pixel still to render in this launch, the current one included
     bool first_counted = false; // the current path's first ray is a queue entry (counted by the host as the queue's length)
-    uint32_t chunk_pos = wave_id * kExtendChunk; // first chunk static, later ones from the cursor (as EXTEND)
-    uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
+    uint32_t chunk_pos = wave_id * chunk_slots; // first chunk static, later ones from the cursor (as EXTEND)
+    uint32_t chunk_end = chunk_pos + chunk_slots < n ? chunk_pos + chunk_slots : n;
     bool exhausted = chunk_pos >= n; // the sample-0 queue has no chunk left for this wave
     if (exhausted) {
         if (!REQ) return;
@@ -730,13 +733,13 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 if (chunk_pos == chunk_end) {
                     if (!exhausted) {
                         uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(cursor, kExtendChunk);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * kExtendChunk;
+                        if (lane == 0) base = atomicAdd(cursor, chunk_slots);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * chunk_slots;
                         if (base >= n) {
                             exhausted = true;
                         } else {
                             chunk_pos = base;
-                            chunk_end = base + kExtendChunk < n ? base + kExtendChunk : n;
+                            chunk_end = base + chunk_slots < n ? base + chunk_slots : n;
                         }
                     }
                     if (REQ && exhausted) { // positions of the dynamic queue, whether their entries exist yet or not
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             }
             if (staged) flush(); // nothing to trace: hand over what this wave still holds
             if (wait_m != 0ull) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(RT_RQ_IDLE_SLEEP); // a wave with nothing to trace must not take issue cycles from those that have
                 continue;
             }
             if (drained) break;
@@ -796,10 +799,12 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
             const bool done_trav = live && T.cur == kTravDone;
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
+            if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
         }
+        if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
 #if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -868,7 +873,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
-        atomicAdd(stats_out + 7, (unsigned long long)ws.top_lanes);
+        atomicAdd(stats_out + 4, (unsigned long long)ws.shade_rounds), atomicAdd(stats_out + 5, (unsigned long long)ws.shade_lanes);
+        atomicAdd(stats_out + 6, (unsigned long long)ws.live_lane_steps), atomicAdd(stats_out + 7, (unsigned long long)ws.top_lanes);
     }
 }
 

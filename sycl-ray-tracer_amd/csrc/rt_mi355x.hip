@@ -439,8 +439,11 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 // persistent grid: wf_finish_occ waves per SIMD for THIS launch. The lanes' launches overlap on the device, so each asks for
                 // its share of the SIMDs' wave slots rather than all of them: fewer, longer-lived waves follow more paths per lane
                 // (less idling at the end of each wave's last paths) and the streams' kernels are resident side by side.
-                const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
-                                                                                    (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K))));
+                const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
+                // queue slots a wave takes at a time: 128 as EXTEND does — but 64 (one per lane) when that is what it takes to give every
+                // resident wave something to do (a 1/8 tile has fewer pixels than the chip has lanes)
+                const uint32_t chunk_slots = L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk;
+                const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + chunk_slots - 1u) / chunk_slots, fin_cap));
                 const uint32_t fin_grid = (fin_waves + fin_wpb - 1u) / fin_wpb;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (r->profile_kernels) { // the dominant kernel of this schedule
@@ -459,7 +462,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
     hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
                        cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
-                       ST ? r->d_stats : (unsigned long long*)nullptr, fq)
+                       ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots)
                 if (r->d_stats && req) RT_FINISH_LAUNCH(true, true);
                 else if (r->d_stats) RT_FINISH_LAUNCH(true, false);
                 else if (req) RT_FINISH_LAUNCH(false, true);
