@@ -644,8 +644,11 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 struct FinishRequeue {
     unsigned long long* entries; // P entries, all ones before the launch
     uint32_t* ctl;               // one 64-byte line each, zero before the launch: [0] tail, [32] head
+    uint32_t* error;             // set when a wave gave up waiting (kRqIdleCap polls with nothing to trace: seconds) — never observed;
+                                 // it turns a logic error into RT_ERR_HIP instead of a hung GPU
     uint32_t capacity;           // >= P (host-sized)
 };
+constexpr uint32_t kRqIdleCap = 1u << 26;
 #ifndef RT_RQ_STAGE
 #define RT_RQ_STAGE 96u
 #endif
@@ -684,6 +687,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
     lds_u64_t* stage = (lds_u64_t*)rq_stage_mem + (threadIdx.x >> 6) * kRqStage; // REQ: this wave's staged entries
     uint32_t staged = 0, stale = 0;                                                // wave-uniform: entries staged, shading rounds since they wait
+    uint32_t idle_polls = 0;                                                       // wave-uniform: consecutive iterations with nothing to trace
     const uint32_t total_entries = REQ ? n * (n_samples - 1u) : 0u;                // P
     const auto accum_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)accum, 0, (int)(n * 16u), 0x00020000); // REQ: 16-byte sc1 accesses
     bool chunk_dq = false; // REQ: the wave's current chunk is a range of POSITIONS of the dynamic queue
@@ -713,6 +717,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every accumulator store this wave has made is at the L2 before an entry names its pixel
         for (uint32_t i = lane; i < staged; i += 64u)
             if (t + i < fq.capacity) rq_store64(fq.entries + t + i, stage[i]);
+        if (lane == 0 && t + staged > fq.capacity) __hip_atomic_store(fq.error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // host-sized: cannot happen
         staged = 0;
     };
     for (;;) {
@@ -790,12 +795,17 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             }
             if (staged) flush(); // nothing to trace: hand over what this wave still holds
             if (wait_m != 0ull) {
+                if (++idle_polls > kRqIdleCap) { // seconds without an entry: give up loudly rather than hang the GPU
+                    if (lane == 0) __hip_atomic_store(fq.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(RT_RQ_IDLE_SLEEP); // a wave with nothing to trace must not take issue cycles from those that have
                 continue;
             }
             if (drained) break;
             continue;
         }
+        idle_polls = 0;
         for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
             const bool done_trav = live && T.cur == kTravDone;
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;

@@ -313,7 +313,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             // spp * (max_depth + 1) queue lengths, spp * max_depth chunk cursors, spp "extra ray" counters of k_wf_finish
             HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
             L.h_counts.resize(nc);
-            L.h_extra.resize(r->spp);
+            L.h_extra.resize((size_t)r->spp + 1); // + the dynamic queue's error word
             const uint32_t chunk = wf_chunk(r, L.n_local);
             if (chunk > 1 && r->wf_requeue) { // every pixel is appended once per sample of a launch but its first
                 L.rq_capacity = L.n_local * (chunk - 1u);
@@ -454,7 +454,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 // rays that are not a queue's length (every bounce beyond D0, every ray of the samples generated in-lane) are counted here
                 uint32_t* extra = cursors + (size_t)r->spp * D + s;
                 const bool req = n_samples > 1 && L.d_rq_entries != nullptr;
-                FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, L.rq_capacity};
+                FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, cursors + (size_t)r->spp * D + r->spp, L.rq_capacity};
                 if (req) { // the launch's dynamic queue: all entries invalid, counters zero
                     HIPCHK(hipMemsetAsync(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls));
                     HIPCHK(hipMemsetAsync(L.d_rq_ctl, 0, 80 * 4, ls));
@@ -650,6 +650,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                 if (!L.n_local) continue;
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(L.h_extra.data(), L.d_counts + L.h_counts.size() + (size_t)r->spp * D, L.h_extra.size() * 4, hipMemcpyDeviceToHost));
+                if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: the dynamic queue stalled or overflowed (internal error word set)");
                 for (uint32_t s = 0; s < r->spp; ++s) {
                     for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407 (queue lengths)
                     rays += L.h_extra[s];                                                        // rays k_wf_finish traced beyond a queue
