@@ -232,11 +232,7 @@ RT_DEV void trav_pop_lds(Trav& T, const TravStack& st) { // caller: stack_shallo
         T.sp -= st.pitch;
         T.cur = *lds_at(T.sp);
     } else {
-#if RT_POSTPONE
-        T.cur = T.pend, T.pend = kTravDone;
-#else
         T.cur = kTravDone;
-#endif
     }
 }
 RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) { // any depth
@@ -251,11 +247,7 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
         const uint32_t e = (T.sp - st.base) / st.pitch;
         T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
     } else {
-#if RT_POSTPONE
-        T.cur = T.pend, T.pend = kTravDone;
-#else
         T.cur = kTravDone;
-#endif
     }
 }
 
@@ -557,6 +549,12 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(__ballot(leaf));
         if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
     }
+#if RT_POSTPONE
+    { // the stack ran dry while a leaf is set aside: it becomes the lane's current node (keeps cur == kTravDone <=> traversal complete)
+        const lmask dry = lanes(T.cur == kTravDone);
+        T.cur = sel(dry, T.cur, T.pend), T.pend = sel(dry, T.pend, kTravDone);
+    }
+#endif
     return ni + nl;
 }
 
