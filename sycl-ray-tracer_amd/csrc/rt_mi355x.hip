@@ -178,6 +178,7 @@ struct rt_renderer {
     // one launch per sample; >= max_depth = the reference's schedule (a launch pair per bounce). RT_WF_FINISH_DEPTH overrides.
     uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
     uint32_t wf_samples_per_launch = RT_WF_SAMPLES_PER_LAUNCH_DEFAULT; // RT_WF_SAMPLES_PER_LAUNCH
+    bool wf_streams_set = false, wf_requeue_set = false; // RT_WF_STREAMS / RT_WF_REQUEUE given: no automatic choice of the regime
     bool wf_requeue = true; // with several samples per launch: breadth first through a device-wide dynamic queue (RT_WF_REQUEUE=0: the lane keeps its pixel)
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
     hipGraphExec_t graph_exec = nullptr;
@@ -243,16 +244,27 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
     return rows;
 }
 
+// The third regime of the wavefront schedule (all three chosen by the tile's size unless the environment says otherwise): a tile with no
+// more pixels than the chip has resident lanes is ONE generation of pixel chains — every pixel gets its lane at once and keeps it for
+// all its samples (depth first, nothing to balance), in one launch on one stream lane: the megakernel's loop fed from a queue.
+// 1/8 of the 1080p frame at 64 spp: 37.0 ms with two stream lanes and the dynamic queue, 31.7 ms this way (megakernel 32.9).
+bool wf_chain_regime(const rt_renderer* r) {
+    return r->wf_samples_per_launch == 0 && !r->wf_streams_set && !r->wf_requeue_set && r->wf_finish_depth == 0 &&
+           (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+}
+bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_chain_regime(r); }
+
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
 // camera ray on; bounded so that a launch's ray counter (32 bits), the entry's 8-bit sample field and the dynamic queue (<= 1 GiB per
 // stream lane) cannot overflow
 uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
     const uint32_t want = r->wf_samples_per_launch ? r->wf_samples_per_launch
+                          : wf_chain_regime(r)                                              ? 256u
                           : (r->wf_requeue && (uint64_t)r->n_local < kStreamingPixels ? kStreamingSamples : 1u);
     if (r->wf_finish_depth != 0 || r->max_depth == 0 || want <= 1 || n_local == 0) return 1u;
     uint64_t c = std::min<uint64_t>(std::min<uint32_t>(want, r->spp), 256u);
     c = std::min<uint64_t>(c, std::max<uint64_t>(1, 0xFFFFFFFFull / ((uint64_t)n_local * r->max_depth)));
-    if (r->wf_requeue) {
+    if (wf_uses_requeue(r)) {
         c = std::min<uint64_t>(c, std::max<uint64_t>(1, ((1ull << 30) / 8) / n_local + 1));
         if (n_local > (1u << 24)) c = 1; // the entry's pixel field has 24 bits
     }
@@ -290,7 +302,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
         }
     } else {
-        uint32_t K = 2;
+        uint32_t K = wf_chain_regime(r) ? 1u : 2u;
         if (const char* e = std::getenv("RT_WF_STREAMS")) K = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
         r->lanes.resize(K);
         for (uint32_t k = 0; k < K; ++k) {
@@ -315,7 +327,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             L.h_counts.resize(nc);
             L.h_extra.resize((size_t)r->spp + 1); // + the dynamic queue's error word
             const uint32_t chunk = wf_chunk(r, L.n_local);
-            if (chunk > 1 && r->wf_requeue) { // every pixel is appended once per sample of a launch but its first
+            if (chunk > 1 && wf_uses_requeue(r)) { // every pixel is appended once per sample of a launch but its first
                 L.rq_capacity = L.n_local * (chunk - 1u);
                 HIPCHK(hipMalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
                 HIPCHK(hipMalloc((void**)&L.d_rq_ctl, 80 * 4));
@@ -884,7 +896,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) r->wf_finish_depth = (uint32_t)std::max(0, std::atoi(e));
         if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(0, std::atoi(e)); // 0 = by tile size
-        if (const char* e = std::getenv("RT_WF_REQUEUE")) r->wf_requeue = e[0] != '0';
+        if (const char* e = std::getenv("RT_WF_REQUEUE")) r->wf_requeue = e[0] != '0', r->wf_requeue_set = true;
+        r->wf_streams_set = std::getenv("RT_WF_STREAMS") != nullptr;
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';
