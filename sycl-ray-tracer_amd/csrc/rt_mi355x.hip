@@ -399,7 +399,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             if (L.n_local == 0) continue;
             buf[k] = 0;
             hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
-                               L.d_counts + (size_t)s * (D + 1));
+                               L.d_counts + (size_t)s * (D + 1), wf_chain_regime(r) ? 1u : 0u);
             launches++;
         }
         for (uint32_t d = 0; d < D0; ++d) {
