@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                 const uint32_t rel = base + rank;
                 const uint32_t p = region * region_slots + rel;
-if (!live && rank < take && rel < region_slots && p < n_slots) start_pixel(p);
+                if (!live && rank < take && rel < region_slots && p < n_slots) start_pixel(p);
                 if (base + take >= region_slots) { // this region is used up: move on to the next one
                     region = (region + 1u) & 7u;
                     last_base = 0;

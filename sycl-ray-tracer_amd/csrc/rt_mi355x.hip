@@ -524,6 +524,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
         constexpr uint32_t mega_wpb = RT_MEGA_BLOCK / 64;
+        // (in the chain regime — fewer tiles than wave slots — 64 pixels on 4,050 waves beat 42 pixels on all 6,144: 29.5 against 33.7 ms)
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
         const uint32_t pad = r->mega_lds_pad;
