@@ -31,7 +31,7 @@ VOP1 = {"v_mov_b32", "v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_cvt_f32_f16", "v
 SHIFT2 = {"v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32"}
 VOP3_3 = {"v_fma_f32", "v_max3_f32", "v_min3_f32", "v_med3_f32", "v_lshl_add_u32", "v_lshl_or_b32", "v_and_or_b32", "v_bfe_u32", "v_bfi_b32",
           "v_perm_b32", "v_add3_u32", "v_mad_u32_u24", "v_alignbit_b32", "v_or3_b32", "v_xad_u32", "v_add_lshl_u32", "v_div_fixup_f32",
-          "v_div_fmas_f32", "v_mad_u64_u32", "v_bfe_i32", "v_mad_i32_i24", "v_med3_i32", "v_med3_u32", "v_max3_u32", "v_min3_u32", "v_max3_i32", "v_min3_i32"}
+          "v_div_fmas_f32", "v_mad_u64_u32", "v_mad_i64_i32", "v_bfe_i32", "v_mad_i32_i24", "v_med3_i32", "v_med3_u32", "v_max3_u32", "v_min3_u32", "v_max3_i32", "v_min3_i32"}
 PACKED = {"v_pk_mul_f32": "v_mul_f32", "v_pk_add_f32": "v_add_f32", "v_pk_fma_f32": "v_fma_f32", "v_mov_b64": "v_mov_b32",
           "v_lshlrev_b64": "v_lshlrev_b32", "v_lshl_add_u64": "v_lshl_add_u32", "v_pk_mov_b32": "v_mov_b32"}
 
@@ -65,7 +65,7 @@ def emit(op, k):
             return f'"{base} {a}, {a}, 2, %8\\n\\t"'
         if base in ("v_bfe_u32", "v_bfe_i32"):
             return f'"{base} {a}, {a}, 8, 8\\n\\t"'
-        if base == "v_mad_u64_u32":
+        if base in ("v_mad_u64_u32", "v_mad_i64_i32"):
             return f'"v_mad_u32_u24 {a}, {a}, %8, %9\\n\\t"'
         return f'"{base} {a}, {a}, %8, %9\\n\\t"'
     if base in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):
