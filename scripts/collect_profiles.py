@@ -1,6 +1,6 @@
 """Copies the round's evidence from gpurun_out/r02/final (scripts/final_profile.sh) into profiles/:
    r02_bench.json, r02_bench_under_rocprof.json, r02_bench_kernel_stats.csv, r02_pmc_bench.json, r02_valu_calibration.json"""
-import collections, csv, glob, json, re, shutil, subprocess, sys
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 F, P = REPO / "gpurun_out" / "r02" / "final", REPO / "profiles"
@@ -9,7 +9,7 @@ shutil.copy(F / "bench_under_rocprof.json", P / "r02_bench_under_rocprof.json")
 for name in ("config_table.txt", "tile_scaling.txt"):
     if (F / name).exists():
         shutil.copy(F / name, P / ("r02_" + name))
-stats = sorted(glob.glob(str(F / "kt" / "**" / "*kernel_stats.csv"), recursive=True))
+stats = sorted(glob.glob(str(F / "kt" / "**" / "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # gpurun_out keeps earlier runs: newest
 if stats:
     rows = list(csv.reader(open(stats[-1])))
     keep = [rows[0]] + [r for r in rows[1:] if "rt::" in r[0]]
@@ -22,7 +22,7 @@ for rend in ("megakernel", "wavefront"):
     for d in glob.glob(str(F / f"pmc_{rend}_*")):
         if not Path(d).is_dir():
             continue
-        files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))
+        files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)  # newest run
         for row in csv.DictReader(open(files[-1])) if files else []:
             m = re.search(r"rt::(k_\w+)", row["Kernel_Name"])
             if m:

@@ -2,7 +2,7 @@
 the measured VALU issue cost per instruction kind (cycles per wave64 instruction and SIMD, by resident waves per SIMD), the cost of the
 render kernels' own static opcode mixes, and what the SQ counters report on a known instruction count (the calibration of
 valu_issue_busy / lane_utilisation in profiles/rNN_valu.json).     python3 scripts/valu_calib_summary.py > profiles/r02_valu_calibration.json"""
-import collections, csv, glob, json, sys
+import os, collections, csv, glob, json, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 R = REPO / "gpurun_out" / "r02"
@@ -27,7 +27,7 @@ def pmc(dirname, under):
     if not f:
         return {}
     rows = collections.defaultdict(dict)
-    for r in csv.DictReader(open(sorted(f)[-1])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):  # gpurun_out keeps earlier runs: the newest
         rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
     ids = sorted(rows)
     out = {}
