@@ -194,8 +194,10 @@ def main() -> int:
                 roof["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
             else:
                 roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
-                roof["schedule"] = f"RT_WF_FINISH_DEPTH={finish_depth}: generate -> compacted queue -> k_wf_finish per sample"
-            roof["concurrent_streams"] = 2  # two sub-tiles on two streams: a launch shares the chip with its twin
+                per_lane = max(hot_launches, 1) / max(args.steps, 1)
+                roof["schedule"] = (f"RT_WF_FINISH_DEPTH={finish_depth}: generate -> compacted queue -> k_wf_finish, {per_lane:g} launches per frame "
+                                    f"for {args.spp} samples (the library picks samples per launch and stream lanes by tile size: DESIGN.md §5)")
+            roof["concurrent_streams"] = int(os.environ.get("RT_WF_STREAMS", "2"))  # sub-tiles on streams of their own share the chip (1 in the chain regime)
             roof["note"] = "incoherent BVH traversal is bound by VALU issue at its lane utilisation; the HBM fraction is small by construction (DESIGN.md §6)"
         else:
             roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache

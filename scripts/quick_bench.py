@@ -16,7 +16,7 @@ for bvh, bname in ((abi.RT_BVH_SAH, "sah"),) + (((abi.RT_BVH_LBVH, "lbvh"),) if 
     cam = Camera.for_scene(sd, (W, H))
     for cls in (WavefrontRenderer, MegakernelRenderer):
         if which != "both" and which not in cls.__name__.lower(): continue
-        r = cls(sc, (W, H), 10, spp)
+        r = cls(sc, (W, H), int(os.environ.get("DEPTH", "10")), spp)
         r.render_frame(cam, want_f32=False, want_u8=False)
         best = None
         for _ in range(3):

@@ -44,8 +44,10 @@ using namespace rt;
 // The queue passes ~1.3 G pixels per second at most, which is less than a launch per sample reaches where paths are cheap: the Cornell
 // box (36 triangles, 5.3 rays per path at 9.9 Grays/s = 1.9 G paths/s), 1024x1024, 64 spp: 36.3 ms a launch per sample, 50.9 ms streaming;
 // the atrium at 18 k / 71 k / 283 k triangles, 1024x1024: +8 % / +15 % / +16 % streaming.
-// Default 0 = choose by tile and scene: 16 samples per launch below kStreamingPixels on scenes of at least kStreamingTriangles
-// triangles, otherwise one launch per sample.
+// Deeper paths make longer tails: 1080p (2.07 M pixels) at depth 10 / 20 / 50, a launch per sample against 16 per launch: 6334 / 5946,
+// 6208 / 6248, 5708 / 6486 Mrays/s — the break-even moves from ~1.5 M pixels at depth 10 to ~2 M at depth 20.
+// Default 0 = choose by tile, depth and scene: 16 samples per launch below kStreamingPixels x sqrt(depth / 10) on scenes of at least
+// kStreamingTriangles triangles, otherwise one launch per sample.
 #ifndef RT_WF_SAMPLES_PER_LAUNCH_DEFAULT
 #define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 0u
 #endif
@@ -264,7 +266,10 @@ bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_chain_r
 uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
     const uint32_t want = r->wf_samples_per_launch ? r->wf_samples_per_launch
                           : wf_chain_regime(r)                                              ? 256u
-                          : (r->wf_requeue && (uint64_t)r->n_local < kStreamingPixels && r->scene->dev.n_tris >= kStreamingTriangles ? kStreamingSamples : 1u);
+                          : (r->wf_requeue && (double)r->n_local < kStreamingPixels * std::sqrt((double)std::max(1u, r->max_depth) / 10.0) &&
+                                     r->scene->dev.n_tris >= kStreamingTriangles
+                                 ? kStreamingSamples
+                                 : 1u);
     if (r->wf_finish_depth != 0 || r->max_depth == 0 || want <= 1 || n_local == 0) return 1u;
     uint64_t c = std::min<uint64_t>(std::min<uint32_t>(want, r->spp), 256u);
     c = std::min<uint64_t>(c, std::max<uint64_t>(1, 0xFFFFFFFFull / ((uint64_t)n_local * r->max_depth)));
