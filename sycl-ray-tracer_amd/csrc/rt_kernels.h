@@ -153,15 +153,30 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
     bool exhausted = false; // wave-uniform: every region's cursor has passed its last slot
+    // RT_MEGA_XCD_REGIONS=1 (round 1's default, now OFF): the frame's pixel slots cut into 8 contiguous regions, one per XCD — a wave
+    // first drains the region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others, so that waves which share an L2 work
+    // on one part of the picture. That paid (+4 %) while the kernel was sensitive to L2 misses; now that it is bound by instruction
+    // issue, what matters is that all waves advance over ONE front and the frame's last pixels are not all in the region that happened
+    // to be slowest: one frame-wide cursor, atrium 1080p 16 spp 38.72 -> 37.83 ms, Cornell box 1024x1024 64 spp 29.8 -> 25.2 ms
+    // (its regions differ a lot in cost: ceiling and light, walls, floor).
+#ifndef RT_MEGA_XCD_REGIONS
+#define RT_MEGA_XCD_REGIONS 0
+#endif
+#if RT_MEGA_XCD_REGIONS
     const uint32_t region_slots = ((n_slots + 7u) / 8u + 63u) & ~63u;
     uint32_t region = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID[3:0]
     uint32_t regions_done = 0;
+#else
+    const uint32_t region_slots = (n_slots + 63u) & ~63u; // one region: the frame
+    uint32_t region = 0;
+    uint32_t regions_done = 7;
+#endif
     const uint32_t region_left = region_slots;                                                  // slots of one region
     const uint32_t waves_per_region = (gridDim.x * (RT_MEGA_BLOCK / 64u) + 7u) / 8u;           // the waves that start on it
     uint32_t last_base = 0; // cursor of the current region as this wave last saw it
     (void)region_left, (void)waves_per_region, (void)last_base; // only read with RT_MEGA_GSS
     auto start_pixel = [&](uint32_t p) { // pixel slot p (8x8-tile order) becomes this lane's pixel; slots outside the image are skipped
-        const uint32_t t = p >> 6;
+        const uint32_t t = p >> 6; // (slots in row order instead of 8x8 blocks: +-0 on both scenes)
         x = (int)((t % tiles_x) * 8u + (p & 7u));
         ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
         gy = tile_global_row(tile, ly);
@@ -212,10 +227,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             }
 #endif
             if (cnt >= RT_MEGA_REFILL && take) {
-                // The frame's pixel slots are cut into 8 contiguous regions, one per XCD: a wave first drains the
-                // region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others. Waves that share an
-                // L2 thus work on one part of the picture, i.e. on the same part of the scene (speed only: any
-                // placement gives the same image).
+                // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -694,7 +706,7 @@ template <bool STATS, bool REQ>
 __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
                                                                     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
-                                                                    uint32_t* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
+                                                                    unsigned long long* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
                                                                     uint32_t n_samples, uint32_t rr_start,
                                                                     unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots) {
     WaveStats ws;
@@ -758,14 +770,18 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             if (cnt >= RT_MEGA_REFILL) {
                 if (chunk_pos == chunk_end) {
                     if (!exhausted) {
+                        // A slot is a whole pixel-chain when the lane keeps its pixel for several samples: then a wave takes exactly as
+                        // many slots as it has idle lanes (as k_megakernel does), never a private chunk that it would still be working
+                        // through when the other waves have left. Single paths are short: there a chunk per atomic is right.
+                        const uint32_t w = !REQ && n_samples > 1u ? cnt : chunk_slots;
                         uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(cursor, chunk_slots);
+                        if (lane == 0) base = atomicAdd(cursor, w);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * chunk_slots;
                         if (base >= n) {
                             exhausted = true;
                         } else {
                             chunk_pos = base;
-                            chunk_end = base + chunk_slots < n ? base + chunk_slots : n;
+                            chunk_end = base + w < n ? base + w : n;
                         }
                     }
                     if (REQ && exhausted) { // positions of the dynamic queue, whether their entries exist yet or not
@@ -900,7 +916,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
 #endif
     }
     const uint32_t total = wave_sum_u32(rays);
-    if (lane == 0 && total) atomicAdd(extra_rays, total);
+    if (lane == 0 && total) atomicAdd(extra_rays, (unsigned long long)total);
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);

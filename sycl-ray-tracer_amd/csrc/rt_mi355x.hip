@@ -31,27 +31,23 @@ using namespace rt;
 #ifndef RT_WF_FINISH_DEPTH_DEFAULT
 #define RT_WF_FINISH_DEPTH_DEFAULT 0u
 #endif
-// Samples k_wf_finish renders per pixel and launch (the streaming schedule, rt_kernels.h). Two forms, both bit-exact for every value:
-//  - depth first (RT_WF_REQUEUE=0): the lane keeps its pixel and generates the next camera ray itself. Atrium 1080p 16 spp, 1 / 2 / 4 /
-//    8 / 16 samples per launch: 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s; config 5's tile 40.3 / - / 42.8 / 43.8 / 43.0 ms: fewer launch
-//    boundaries, but the launch ends with its slowest pixel-CHUNK: the tail grows as fast as the boundaries vanish.
-//  - breadth first (default form): the pixel goes through a device-wide dynamic queue to whichever lane is idle, so a launch ends with
-//    single paths. Depth 10, 16 spp, by frame size, Mrays/s at 1 / 4 / 16 samples per launch: 960x540 4253 / 4244 / 4368; 1920x540
-//    5081 / 5830 / 5869; 1920x1080 6334 / 6179 / 5946; 2560x1440 6825 / 6230 / 6025; 3840x2160 7032 / 6248 / 5843; config 5's tile
-//    (1.04 M pixels, depth 16) 40.0 / 33.3 / 32.8 ms against the megakernel's 30.6. The queue costs ~12 % more VALU instructions and
-//    ~30 % more L2 misses (a wave's pixels are no longer neighbours after their first sample) and levels off at ~6.0 Grays/s, while
-//    a launch per sample climbs with the frame as its tails amortise: streaming wins below ~1.5 M pixels per GPU and loses above.
-// The queue passes ~1.3 G pixels per second at most, which is less than a launch per sample reaches where paths are cheap: the Cornell
-// box (36 triangles, 5.3 rays per path at 9.9 Grays/s = 1.9 G paths/s), 1024x1024, 64 spp: 36.3 ms a launch per sample, 50.9 ms streaming;
-// the atrium at 18 k / 71 k / 283 k triangles, 1024x1024: +8 % / +15 % / +16 % streaming.
-// Deeper paths make longer tails: 1080p (2.07 M pixels) at depth 10 / 20 / 50, a launch per sample against 16 per launch: 6334 / 5946,
-// 6208 / 6248, 5708 / 6486 Mrays/s — the break-even moves from ~1.5 M pixels at depth 10 to ~2 M at depth 20.
-// Default 0 = choose by tile, depth and scene: 16 samples per launch below kStreamingPixels x sqrt(depth / 10) on scenes of at least
-// kStreamingTriangles triangles, otherwise one launch per sample.
+// Samples k_wf_finish renders per pixel and launch (RT_WF_SAMPLES_PER_LAUNCH). 0, the default, is the ONE-LAUNCH schedule: all samples in
+// one launch per frame and tile on one stream lane, the lane keeps its pixel (depth first) and a wave takes exactly as many queue slots as
+// it has idle lanes — the megakernel's loop fed from a queue, and as fast: atrium 1080p 64 spp 151.7 ms (megakernel 149.8), 1/2 / 1/4 /
+// 1/8 of it 82.0 / 51.0 / 29.4 ms (81.5 / 50.9 / 29.6), config 5's tile 462 ms (454), the full 4K frame at 16 spp 142.5 ms (140.8).
+// A positive value selects the earlier schedules, all bit-exact, on two stream lanes (RT_WF_STREAMS):
+//  - 1: a launch per sample (the reference's shape minus its per-bounce launches): 167.9 ms at 1080p 64 spp; every launch ends with its
+//    slowest paths while its half of the machine idles;
+//  - C > 1, breadth first (RT_WF_REQUEUE=1, default): a pixel between two samples goes through a device-wide dynamic queue to whichever
+//    lane is idle. Depth 10, 16 spp, Mrays/s at C = 1 / 4 / 16: 960x540 4253 / 4244 / 4368; 1920x540 5081 / 5830 / 5869; 1920x1080 6334 /
+//    6179 / 5946; 3840x2160 7032 / 6248 / 5843: it levels off at ~6.0 Grays/s (+12 % VALU instructions, +32 % L2 misses: a wave's pixels
+//    are no longer neighbours) and passes ~1.3 G pixels per second at most (Cornell box: 36.2 ms a launch per sample, 50.9 ms streaming);
+//    it wins over a launch per sample on small tiles and deep paths (config 5's tile 629 -> 495 ms; 1080p depth 50: 5708 -> 6486 Mrays/s);
+//  - C > 1, depth first on two stream lanes (RT_WF_REQUEUE=0): 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s for C = 1 / 2 / 4 / 8 / 16 at 1080p
+//    16 spp when waves took private 128-slot chunks (whole pixel-chains: the launch ended with a few waves working through theirs).
 #ifndef RT_WF_SAMPLES_PER_LAUNCH_DEFAULT
 #define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 0u
 #endif
-constexpr uint32_t kStreamingPixels = 1500000u, kStreamingSamples = 16u, kStreamingTriangles = 4096u;
 
 namespace {
 
@@ -159,7 +155,9 @@ struct rt_renderer {
         unsigned long long* d_rq_entries = nullptr;
         uint32_t* d_rq_ctl = nullptr;
         uint32_t rq_capacity = 0;
-        std::vector<uint32_t> h_counts, h_extra;
+        std::vector<uint32_t> h_counts;
+        unsigned long long* d_extra = nullptr; // per launch: rays k_wf_finish traced beyond its queue's length; [spp]: the dynamic queue's error word
+        std::vector<unsigned long long> h_extra;
         hipStream_t stream = nullptr;
         hipEvent_t ev_done = nullptr;
         std::vector<hipEvent_t> ev_pool;
@@ -226,7 +224,7 @@ void free_tile_buffers(rt_renderer* r) {
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
     fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
     for (auto& L : r->lanes) {
-        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl);
+        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
@@ -250,30 +248,25 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
     return rows;
 }
 
-// The third regime of the wavefront schedule (all three chosen by the tile's size unless the environment says otherwise): a tile with no
-// more pixels than the chip has resident lanes is ONE generation of pixel chains — every pixel gets its lane at once and keeps it for
-// all its samples (depth first, nothing to balance), in one launch on one stream lane: the megakernel's loop fed from a queue.
-// 1/8 of the 1080p frame at 64 spp: 37.0 ms with two stream lanes and the dynamic queue, 31.7 ms this way (megakernel 32.9).
-bool wf_chain_regime(const rt_renderer* r) {
-    return r->wf_samples_per_launch == 0 && !r->wf_streams_set && !r->wf_requeue_set && r->wf_finish_depth == 0 &&
-           (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+// The wavefront renderer's default schedule: ONE k_wf_generate + ONE k_wf_finish launch per frame and tile, on one stream lane, every
+// pixel kept in its lane for all its samples (rt_kernels.h). It applies unless the environment asks for one of the other schedules
+// (RT_WF_SAMPLES_PER_LAUNCH, RT_WF_REQUEUE, RT_WF_STREAMS, RT_WF_FINISH_DEPTH), which stay in the tree with their tests.
+bool wf_one_launch(const rt_renderer* r) {
+    return r->wf_samples_per_launch == 0 && !r->wf_streams_set && !r->wf_requeue_set && r->wf_finish_depth == 0 && r->max_depth > 0;
 }
-bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_chain_regime(r); }
+// ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
+// hands every wave pixels spread evenly over the tile
+bool wf_spread(const rt_renderer* r) { return wf_one_launch(r) && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u; }
+bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_one_launch(r); }
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
-// camera ray on; bounded so that a launch's ray counter (32 bits), the entry's 8-bit sample field and the dynamic queue (<= 1 GiB per
-// stream lane) cannot overflow
+// camera ray on; with the dynamic queue bounded by the entry's 8-bit sample field and the queue's size (<= 1 GiB per stream lane)
 uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
-    const uint32_t want = r->wf_samples_per_launch ? r->wf_samples_per_launch
-                          : wf_chain_regime(r)                                              ? 256u
-                          : (r->wf_requeue && (double)r->n_local < kStreamingPixels * std::sqrt((double)std::max(1u, r->max_depth) / 10.0) &&
-                                     r->scene->dev.n_tris >= kStreamingTriangles
-                                 ? kStreamingSamples
-                                 : 1u);
-    if (r->wf_finish_depth != 0 || r->max_depth == 0 || want <= 1 || n_local == 0) return 1u;
-    uint64_t c = std::min<uint64_t>(std::min<uint32_t>(want, r->spp), 256u);
-    c = std::min<uint64_t>(c, std::max<uint64_t>(1, 0xFFFFFFFFull / ((uint64_t)n_local * r->max_depth)));
+    if (r->wf_finish_depth != 0 || r->max_depth == 0 || n_local == 0) return 1u;
+    if (wf_one_launch(r)) return r->spp;
+    uint64_t c = std::min<uint32_t>(std::max(1u, r->wf_samples_per_launch), r->spp);
     if (wf_uses_requeue(r)) {
+        c = std::min<uint64_t>(c, 256u);
         c = std::min<uint64_t>(c, std::max<uint64_t>(1, ((1ull << 30) / 8) / n_local + 1));
         if (n_local > (1u << 24)) c = 1; // the entry's pixel field has 24 bits
     }
@@ -311,7 +304,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
         }
     } else {
-        uint32_t K = wf_chain_regime(r) ? 1u : 2u;
+        uint32_t K = wf_one_launch(r) ? 1u : 2u;
         if (const char* e = std::getenv("RT_WF_STREAMS")) K = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
         r->lanes.resize(K);
         for (uint32_t k = 0; k < K; ++k) {
@@ -335,6 +328,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
             L.h_counts.resize(nc);
             L.h_extra.resize((size_t)r->spp + 1); // + the dynamic queue's error word
+            HIPCHK(hipMalloc((void**)&L.d_extra, L.h_extra.size() * 8));
             const uint32_t chunk = wf_chunk(r, L.n_local);
             if (chunk > 1 && wf_uses_requeue(r)) { // every pixel is appended once per sample of a launch but its first
                 L.rq_capacity = L.n_local * (chunk - 1u);
@@ -391,6 +385,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                                                                             (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
         HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, L.stream));
+        HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, L.stream));
         hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
         launches++;
     }
@@ -408,7 +403,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             if (L.n_local == 0) continue;
             buf[k] = 0;
             hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
-                               L.d_counts + (size_t)s * (D + 1), wf_chain_regime(r) ? 1u : 0u);
+                               L.d_counts + (size_t)s * (D + 1), wf_spread(r) ? 1u : 0u);
             launches++;
         }
         for (uint32_t d = 0; d < D0; ++d) {
@@ -463,7 +458,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
                 // queue slots a wave takes at a time: 128 as EXTEND does — but 64 (one per lane) when that is what it takes to give every
                 // resident wave something to do (a 1/8 tile has fewer pixels than the chip has lanes)
-                const uint32_t chunk_slots = L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk;
+                const uint32_t chunk_slots = (L.n_local < 2u * 64u * fin_cap || (n_samples > 1 && !L.d_rq_entries)) ? 64u : kExtendChunk;
                 const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + chunk_slots - 1u) / chunk_slots, fin_cap));
                 const uint32_t fin_grid = (fin_waves + fin_wpb - 1u) / fin_wpb;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -473,9 +468,9 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     HIPCHK(hipEventRecord(e0, ls));
                 }
                 // rays that are not a queue's length (every bounce beyond D0, every ray of the samples generated in-lane) are counted here
-                uint32_t* extra = cursors + (size_t)r->spp * D + s;
+                unsigned long long* extra = L.d_extra + s;
                 const bool req = n_samples > 1 && L.d_rq_entries != nullptr;
-                FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, cursors + (size_t)r->spp * D + r->spp, L.rq_capacity};
+                FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, reinterpret_cast<uint32_t*>(L.d_extra + r->spp), L.rq_capacity};
                 if (req) { // the launch's dynamic queue: all entries invalid, counters zero
                     HIPCHK(hipMemsetAsync(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls));
                     HIPCHK(hipMemsetAsync(L.d_rq_ctl, 0, 80 * 4, ls));
@@ -671,7 +666,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
             for (auto& L : r->lanes) {
                 if (!L.n_local) continue;
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(L.h_extra.data(), L.d_counts + L.h_counts.size() + (size_t)r->spp * D, L.h_extra.size() * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(L.h_extra.data(), L.d_extra, L.h_extra.size() * 8, hipMemcpyDeviceToHost));
                 if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: the dynamic queue stalled or overflowed (internal error word set)");
                 for (uint32_t s = 0; s < r->spp; ++s) {
                     for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407 (queue lengths)
