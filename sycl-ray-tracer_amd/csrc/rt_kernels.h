@@ -649,12 +649,13 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 // What it removes: (max_depth - first_depth) x 2 dependent launches per sample with their drain tails, the hit-record round trip
 // and the 68 B/ray queue write + read of every later bounce. Rays traced beyond bounce `first_depth` are counted into *extra_rays
 // (the queue lengths the host sums stop at first_depth).
-// n_samples > 1 (only with first_depth == 0): the streaming schedule. A pixel's samples are sequential (its RNG word), but pixels
-// are independent, so the lane whose path has ended generates the SAME pixel's next camera ray itself — Camera::get_ray with the RNG
-// word it holds in a register, exactly what k_wf_generate would do after reading that word back from memory — and goes on, for
-// n_samples samples, before it stores the word and takes the next queue slot. This removes the per-sample launch boundary and its
-// drain tail as well (the queue then feeds only the chunk's first sample).
-// n_samples > 1 with a FinishRequeue (REQ, the streaming schedule): breadth first instead of depth first. The lane whose path has ended
+// n_samples > 1 (only with first_depth == 0; the renderer's default is n_samples = spp: ONE launch per frame). A pixel's samples are
+// sequential (its RNG word), but pixels are independent, so the lane whose path has ended generates the SAME pixel's next camera ray
+// itself — Camera::get_ray with the RNG word it holds in a register, exactly what k_wf_generate would do after reading that word back
+// from memory — and goes on, for n_samples samples, before it stores the word and takes the next queue slot. A queue slot is then a
+// whole pixel-chain, so a wave takes exactly as many slots as it has idle lanes (below): this is k_megakernel's loop fed from a
+// queue, and as fast.
+// n_samples > 1 with a FinishRequeue (REQ; RT_WF_SAMPLES_PER_LAUNCH=C with RT_WF_REQUEUE=1): breadth first instead of depth first. The lane whose path has ended
 // does not keep the pixel: it appends (pixel, samples left, RNG word) to a DEVICE-WIDE dynamic queue; any lane that is idle once the
 // sample-0 queue is used up takes the pixel from there and generates its next camera ray with the word it finds in the entry (what
 // k_wf_generate does after reading the word back from rng_buf). All pixels thus advance through their samples together and a launch
