@@ -378,6 +378,32 @@ def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypa
         r.close()
 
 
+@pytest.mark.parametrize("env", [{"RT_WF_STREAMS": "2"}, {"RT_WF_STREAMS": "3"}, {"RT_WF_REQUEUE": "0"}, {"RT_WF_STREAMS": "1", "RT_WF_SAMPLES_PER_LAUNCH": "2"},
+                                 {"RT_WF_STREAMS": "4", "RT_WF_SAMPLES_PER_LAUNCH": "3", "RT_WF_REQUEUE": "1"}, {"RT_WF_FINISH_DEPTH": "2", "RT_WF_STREAMS": "1"}],
+                         ids=lambda e: ",".join(f"{k[6:].lower()}={v}" for k, v in e.items()))
+def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, monkeypatch, env):
+    """Any of the schedule's environment variables switches the wavefront renderer from its default (one launch per frame on one stream
+    lane) to the schedules with several launches: stream lanes x samples per launch x hand-over form x per-bounce depth. Whatever the
+    combination, frame, unorm8 image and ray count are the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 5), ("atrium", {"detail": 1}, (200, 120), 10, 4)):
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+        osc = oracle.OracleScene(sd)
+        r = WavefrontRenderer(gs, (w, h), depth, spp)
+        got = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {env}")
+        r.set_tile(2, 3, 8)
+        tile = r.render_frame(cam)
+        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=2, world=3, strip_rows=8)
+        _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} {env} tile 2/3")
+        r.close()
+
+
 @pytest.mark.parametrize("finish_depth", [0, 1, 3, 7, 8, 99])
 def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, monkeypatch, finish_depth):
     """The wavefront renderer's schedule: the first RT_WF_FINISH_DEPTH bounces launch by launch (EXTEND + SHADE with global
