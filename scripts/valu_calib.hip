@@ -23,6 +23,15 @@
 
 #include "valu_mix_count.inc" // kMixCount_trav, kMixCount_mega, kMixHist_*
 
+// REPn(x): the string literal(s) x, n times (the asm bodies below are one period of their instruction pattern, repeated)
+#define REP2(x) x x
+#define REP4(x) REP2(x) REP2(x)
+#define REP8(x) REP4(x) REP4(x)
+#define REP16(x) REP8(x) REP8(x)
+#define REP32(x) REP16(x) REP16(x)
+#define REP64(x) REP32(x) REP32(x)
+#define REP128(x) REP64(x) REP64(x)
+
 #define CHK(e)                                                                                  \
     do {                                                                                        \
         hipError_t e_ = (e);                                                                    \
@@ -133,7 +142,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
     // ONE asm statement per loop iteration: the compiler puts nothing between the measured instructions
     for (uint32_t i = 0; i < iters; ++i) {
         if (OP == FMA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_fma_f32 %0, %0, %8, %9\n\t"
             "v_fma_f32 %1, %1, %8, %9\n\t"
             "v_fma_f32 %2, %2, %8, %9\n\t"
@@ -142,130 +151,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_fma_f32 %5, %5, %8, %9\n\t"
             "v_fma_f32 %6, %6, %8, %9\n\t"
             "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MUL) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mul_f32 %0, %0, %8\n\t"
             "v_mul_f32 %1, %1, %8\n\t"
             "v_mul_f32 %2, %2, %8\n\t"
@@ -274,130 +164,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mul_f32 %5, %5, %8\n\t"
             "v_mul_f32 %6, %6, %8\n\t"
             "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
-            "v_mul_f32 %0, %0, %8\n\t"
-            "v_mul_f32 %1, %1, %8\n\t"
-            "v_mul_f32 %2, %2, %8\n\t"
-            "v_mul_f32 %3, %3, %8\n\t"
-            "v_mul_f32 %4, %4, %8\n\t"
-            "v_mul_f32 %5, %5, %8\n\t"
-            "v_mul_f32 %6, %6, %8\n\t"
-            "v_mul_f32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ADD_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_add_f32 %0, %0, %9\n\t"
             "v_add_f32 %1, %1, %9\n\t"
             "v_add_f32 %2, %2, %9\n\t"
@@ -406,130 +177,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_add_f32 %5, %5, %9\n\t"
             "v_add_f32 %6, %6, %9\n\t"
             "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
-            "v_add_f32 %0, %0, %9\n\t"
-            "v_add_f32 %1, %1, %9\n\t"
-            "v_add_f32 %2, %2, %9\n\t"
-            "v_add_f32 %3, %3, %9\n\t"
-            "v_add_f32 %4, %4, %9\n\t"
-            "v_add_f32 %5, %5, %9\n\t"
-            "v_add_f32 %6, %6, %9\n\t"
-            "v_add_f32 %7, %7, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == SUB_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_sub_f32 %0, %0, %9\n\t"
             "v_sub_f32 %1, %1, %9\n\t"
             "v_sub_f32 %2, %2, %9\n\t"
@@ -538,130 +190,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_sub_f32 %5, %5, %9\n\t"
             "v_sub_f32 %6, %6, %9\n\t"
             "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
-            "v_sub_f32 %0, %0, %9\n\t"
-            "v_sub_f32 %1, %1, %9\n\t"
-            "v_sub_f32 %2, %2, %9\n\t"
-            "v_sub_f32 %3, %3, %9\n\t"
-            "v_sub_f32 %4, %4, %9\n\t"
-            "v_sub_f32 %5, %5, %9\n\t"
-            "v_sub_f32 %6, %6, %9\n\t"
-            "v_sub_f32 %7, %7, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FMAC) {
-            asm volatile(
+            asm volatile(REP16(
             "v_fmac_f32 %0, %8, %9\n\t"
             "v_fmac_f32 %1, %8, %9\n\t"
             "v_fmac_f32 %2, %8, %9\n\t"
@@ -670,130 +203,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_fmac_f32 %5, %8, %9\n\t"
             "v_fmac_f32 %6, %8, %9\n\t"
             "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
-            "v_fmac_f32 %0, %8, %9\n\t"
-            "v_fmac_f32 %1, %8, %9\n\t"
-            "v_fmac_f32 %2, %8, %9\n\t"
-            "v_fmac_f32 %3, %8, %9\n\t"
-            "v_fmac_f32 %4, %8, %9\n\t"
-            "v_fmac_f32 %5, %8, %9\n\t"
-            "v_fmac_f32 %6, %8, %9\n\t"
-            "v_fmac_f32 %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MOV) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mov_b32 %0, %8\n\t"
             "v_mov_b32 %1, %8\n\t"
             "v_mov_b32 %2, %8\n\t"
@@ -802,130 +216,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mov_b32 %5, %8\n\t"
             "v_mov_b32 %6, %8\n\t"
             "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
-            "v_mov_b32 %0, %8\n\t"
-            "v_mov_b32 %1, %8\n\t"
-            "v_mov_b32 %2, %8\n\t"
-            "v_mov_b32 %3, %8\n\t"
-            "v_mov_b32 %4, %8\n\t"
-            "v_mov_b32 %5, %8\n\t"
-            "v_mov_b32 %6, %8\n\t"
-            "v_mov_b32 %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == AND) {
-            asm volatile(
+            asm volatile(REP16(
             "v_and_b32 %0, %0, %8\n\t"
             "v_and_b32 %1, %1, %8\n\t"
             "v_and_b32 %2, %2, %8\n\t"
@@ -934,130 +229,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_and_b32 %5, %5, %8\n\t"
             "v_and_b32 %6, %6, %8\n\t"
             "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
-            "v_and_b32 %0, %0, %8\n\t"
-            "v_and_b32 %1, %1, %8\n\t"
-            "v_and_b32 %2, %2, %8\n\t"
-            "v_and_b32 %3, %3, %8\n\t"
-            "v_and_b32 %4, %4, %8\n\t"
-            "v_and_b32 %5, %5, %8\n\t"
-            "v_and_b32 %6, %6, %8\n\t"
-            "v_and_b32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == OR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_or_b32 %0, %0, %8\n\t"
             "v_or_b32 %1, %1, %8\n\t"
             "v_or_b32 %2, %2, %8\n\t"
@@ -1066,130 +242,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_or_b32 %5, %5, %8\n\t"
             "v_or_b32 %6, %6, %8\n\t"
             "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
-            "v_or_b32 %0, %0, %8\n\t"
-            "v_or_b32 %1, %1, %8\n\t"
-            "v_or_b32 %2, %2, %8\n\t"
-            "v_or_b32 %3, %3, %8\n\t"
-            "v_or_b32 %4, %4, %8\n\t"
-            "v_or_b32 %5, %5, %8\n\t"
-            "v_or_b32 %6, %6, %8\n\t"
-            "v_or_b32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == XOR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_xor_b32 %0, %0, %8\n\t"
             "v_xor_b32 %1, %1, %8\n\t"
             "v_xor_b32 %2, %2, %8\n\t"
@@ -1198,130 +255,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_xor_b32 %5, %5, %8\n\t"
             "v_xor_b32 %6, %6, %8\n\t"
             "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
-            "v_xor_b32 %0, %0, %8\n\t"
-            "v_xor_b32 %1, %1, %8\n\t"
-            "v_xor_b32 %2, %2, %8\n\t"
-            "v_xor_b32 %3, %3, %8\n\t"
-            "v_xor_b32 %4, %4, %8\n\t"
-            "v_xor_b32 %5, %5, %8\n\t"
-            "v_xor_b32 %6, %6, %8\n\t"
-            "v_xor_b32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ADD_U32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_add_u32 %0, %0, %8\n\t"
             "v_add_u32 %1, %1, %8\n\t"
             "v_add_u32 %2, %2, %8\n\t"
@@ -1330,130 +268,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_add_u32 %5, %5, %8\n\t"
             "v_add_u32 %6, %6, %8\n\t"
             "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
-            "v_add_u32 %0, %0, %8\n\t"
-            "v_add_u32 %1, %1, %8\n\t"
-            "v_add_u32 %2, %2, %8\n\t"
-            "v_add_u32 %3, %3, %8\n\t"
-            "v_add_u32 %4, %4, %8\n\t"
-            "v_add_u32 %5, %5, %8\n\t"
-            "v_add_u32 %6, %6, %8\n\t"
-            "v_add_u32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == SUB_U32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_sub_u32 %0, %0, %8\n\t"
             "v_sub_u32 %1, %1, %8\n\t"
             "v_sub_u32 %2, %2, %8\n\t"
@@ -1462,130 +281,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_sub_u32 %5, %5, %8\n\t"
             "v_sub_u32 %6, %6, %8\n\t"
             "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
-            "v_sub_u32 %0, %0, %8\n\t"
-            "v_sub_u32 %1, %1, %8\n\t"
-            "v_sub_u32 %2, %2, %8\n\t"
-            "v_sub_u32 %3, %3, %8\n\t"
-            "v_sub_u32 %4, %4, %8\n\t"
-            "v_sub_u32 %5, %5, %8\n\t"
-            "v_sub_u32 %6, %6, %8\n\t"
-            "v_sub_u32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MUL_U24) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mul_u32_u24 %0, %0, %8\n\t"
             "v_mul_u32_u24 %1, %1, %8\n\t"
             "v_mul_u32_u24 %2, %2, %8\n\t"
@@ -1594,130 +294,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mul_u32_u24 %5, %5, %8\n\t"
             "v_mul_u32_u24 %6, %6, %8\n\t"
             "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
-            "v_mul_u32_u24 %0, %0, %8\n\t"
-            "v_mul_u32_u24 %1, %1, %8\n\t"
-            "v_mul_u32_u24 %2, %2, %8\n\t"
-            "v_mul_u32_u24 %3, %3, %8\n\t"
-            "v_mul_u32_u24 %4, %4, %8\n\t"
-            "v_mul_u32_u24 %5, %5, %8\n\t"
-            "v_mul_u32_u24 %6, %6, %8\n\t"
-            "v_mul_u32_u24 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MAD_U24) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mad_u32_u24 %0, %0, %8, %9\n\t"
             "v_mad_u32_u24 %1, %1, %8, %9\n\t"
             "v_mad_u32_u24 %2, %2, %8, %9\n\t"
@@ -1726,262 +307,17 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mad_u32_u24 %5, %5, %8, %9\n\t"
             "v_mad_u32_u24 %6, %6, %8, %9\n\t"
             "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-            "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-            "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-            "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-            "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-            "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-            "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-            "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-            "v_mad_u32_u24 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FMA_DEP) {
-            asm volatile(
+            asm volatile(REP128(
             "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FMA_HALF_EXEC) {
-            asm volatile(
+            asm volatile(REP16(
             "v_fma_f32 %0, %0, %8, %9\n\t"
             "v_fma_f32 %1, %1, %8, %9\n\t"
             "v_fma_f32 %2, %2, %8, %9\n\t"
@@ -1990,130 +326,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_fma_f32 %5, %5, %8, %9\n\t"
             "v_fma_f32 %6, %6, %8, %9\n\t"
             "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
-            "v_fma_f32 %0, %0, %8, %9\n\t"
-            "v_fma_f32 %1, %1, %8, %9\n\t"
-            "v_fma_f32 %2, %2, %8, %9\n\t"
-            "v_fma_f32 %3, %3, %8, %9\n\t"
-            "v_fma_f32 %4, %4, %8, %9\n\t"
-            "v_fma_f32 %5, %5, %8, %9\n\t"
-            "v_fma_f32 %6, %6, %8, %9\n\t"
-            "v_fma_f32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FMA_MIX) {
-            asm volatile(
+            asm volatile(REP16(
             "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
@@ -2122,130 +339,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FMA_MIX_HI) {
-            asm volatile(
+            asm volatile(REP16(
             "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -2254,130 +352,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %0, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %1, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %2, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %3, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %4, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %5, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %6, %6, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %7, %7, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == PK_FMA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_pk_fma_f32 %0, %0, %8, %9\n\t"
             "v_pk_fma_f32 %1, %1, %8, %9\n\t"
             "v_pk_fma_f32 %2, %2, %8, %9\n\t"
@@ -2386,130 +365,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_pk_fma_f32 %5, %5, %8, %9\n\t"
             "v_pk_fma_f32 %6, %6, %8, %9\n\t"
             "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f32 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f32 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f32 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f32 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f32 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f32 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f32 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f32 %7, %7, %8, %9\n\t"
+            )
               : PACC8 : "v"(pb), "v"(pc));
         }
         else if (OP == PK_MUL) {
-            asm volatile(
+            asm volatile(REP16(
             "v_pk_mul_f32 %0, %0, %8\n\t"
             "v_pk_mul_f32 %1, %1, %8\n\t"
             "v_pk_mul_f32 %2, %2, %8\n\t"
@@ -2518,130 +378,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_pk_mul_f32 %5, %5, %8\n\t"
             "v_pk_mul_f32 %6, %6, %8\n\t"
             "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
-            "v_pk_mul_f32 %0, %0, %8\n\t"
-            "v_pk_mul_f32 %1, %1, %8\n\t"
-            "v_pk_mul_f32 %2, %2, %8\n\t"
-            "v_pk_mul_f32 %3, %3, %8\n\t"
-            "v_pk_mul_f32 %4, %4, %8\n\t"
-            "v_pk_mul_f32 %5, %5, %8\n\t"
-            "v_pk_mul_f32 %6, %6, %8\n\t"
-            "v_pk_mul_f32 %7, %7, %8\n\t"
+            )
               : PACC8 : "v"(pb), "v"(pc));
         }
         else if (OP == PK_ADD) {
-            asm volatile(
+            asm volatile(REP16(
             "v_pk_add_f32 %0, %0, %8\n\t"
             "v_pk_add_f32 %1, %1, %8\n\t"
             "v_pk_add_f32 %2, %2, %8\n\t"
@@ -2650,130 +391,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_pk_add_f32 %5, %5, %8\n\t"
             "v_pk_add_f32 %6, %6, %8\n\t"
             "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
-            "v_pk_add_f32 %0, %0, %8\n\t"
-            "v_pk_add_f32 %1, %1, %8\n\t"
-            "v_pk_add_f32 %2, %2, %8\n\t"
-            "v_pk_add_f32 %3, %3, %8\n\t"
-            "v_pk_add_f32 %4, %4, %8\n\t"
-            "v_pk_add_f32 %5, %5, %8\n\t"
-            "v_pk_add_f32 %6, %6, %8\n\t"
-            "v_pk_add_f32 %7, %7, %8\n\t"
+            )
               : PACC8 : "v"(pb), "v"(pc));
         }
         else if (OP == PK_FMA_F16) {
-            asm volatile(
+            asm volatile(REP16(
             "v_pk_fma_f16 %0, %0, %8, %9\n\t"
             "v_pk_fma_f16 %1, %1, %8, %9\n\t"
             "v_pk_fma_f16 %2, %2, %8, %9\n\t"
@@ -2782,130 +404,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_pk_fma_f16 %5, %5, %8, %9\n\t"
             "v_pk_fma_f16 %6, %6, %8, %9\n\t"
             "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
-            "v_pk_fma_f16 %0, %0, %8, %9\n\t"
-            "v_pk_fma_f16 %1, %1, %8, %9\n\t"
-            "v_pk_fma_f16 %2, %2, %8, %9\n\t"
-            "v_pk_fma_f16 %3, %3, %8, %9\n\t"
-            "v_pk_fma_f16 %4, %4, %8, %9\n\t"
-            "v_pk_fma_f16 %5, %5, %8, %9\n\t"
-            "v_pk_fma_f16 %6, %6, %8, %9\n\t"
-            "v_pk_fma_f16 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == PK_MAX_F16) {
-            asm volatile(
+            asm volatile(REP16(
             "v_pk_max_f16 %0, %0, %8\n\t"
             "v_pk_max_f16 %1, %1, %8\n\t"
             "v_pk_max_f16 %2, %2, %8\n\t"
@@ -2914,130 +417,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_pk_max_f16 %5, %5, %8\n\t"
             "v_pk_max_f16 %6, %6, %8\n\t"
             "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
-            "v_pk_max_f16 %0, %0, %8\n\t"
-            "v_pk_max_f16 %1, %1, %8\n\t"
-            "v_pk_max_f16 %2, %2, %8\n\t"
-            "v_pk_max_f16 %3, %3, %8\n\t"
-            "v_pk_max_f16 %4, %4, %8\n\t"
-            "v_pk_max_f16 %5, %5, %8\n\t"
-            "v_pk_max_f16 %6, %6, %8\n\t"
-            "v_pk_max_f16 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LSHL) {
-            asm volatile(
+            asm volatile(REP16(
             "v_lshlrev_b32 %0, 1, %0\n\t"
             "v_lshlrev_b32 %1, 1, %1\n\t"
             "v_lshlrev_b32 %2, 1, %2\n\t"
@@ -3046,130 +430,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_lshlrev_b32 %5, 1, %5\n\t"
             "v_lshlrev_b32 %6, 1, %6\n\t"
             "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
-            "v_lshlrev_b32 %0, 1, %0\n\t"
-            "v_lshlrev_b32 %1, 1, %1\n\t"
-            "v_lshlrev_b32 %2, 1, %2\n\t"
-            "v_lshlrev_b32 %3, 1, %3\n\t"
-            "v_lshlrev_b32 %4, 1, %4\n\t"
-            "v_lshlrev_b32 %5, 1, %5\n\t"
-            "v_lshlrev_b32 %6, 1, %6\n\t"
-            "v_lshlrev_b32 %7, 1, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LSHR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_lshrrev_b32 %0, 1, %0\n\t"
             "v_lshrrev_b32 %1, 1, %1\n\t"
             "v_lshrrev_b32 %2, 1, %2\n\t"
@@ -3178,130 +443,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_lshrrev_b32 %5, 1, %5\n\t"
             "v_lshrrev_b32 %6, 1, %6\n\t"
             "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
-            "v_lshrrev_b32 %0, 1, %0\n\t"
-            "v_lshrrev_b32 %1, 1, %1\n\t"
-            "v_lshrrev_b32 %2, 1, %2\n\t"
-            "v_lshrrev_b32 %3, 1, %3\n\t"
-            "v_lshrrev_b32 %4, 1, %4\n\t"
-            "v_lshrrev_b32 %5, 1, %5\n\t"
-            "v_lshrrev_b32 %6, 1, %6\n\t"
-            "v_lshrrev_b32 %7, 1, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ASHR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_ashrrev_i32 %0, 1, %0\n\t"
             "v_ashrrev_i32 %1, 1, %1\n\t"
             "v_ashrrev_i32 %2, 1, %2\n\t"
@@ -3310,130 +456,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_ashrrev_i32 %5, 1, %5\n\t"
             "v_ashrrev_i32 %6, 1, %6\n\t"
             "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
-            "v_ashrrev_i32 %0, 1, %0\n\t"
-            "v_ashrrev_i32 %1, 1, %1\n\t"
-            "v_ashrrev_i32 %2, 1, %2\n\t"
-            "v_ashrrev_i32 %3, 1, %3\n\t"
-            "v_ashrrev_i32 %4, 1, %4\n\t"
-            "v_ashrrev_i32 %5, 1, %5\n\t"
-            "v_ashrrev_i32 %6, 1, %6\n\t"
-            "v_ashrrev_i32 %7, 1, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LSHL_OR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_lshl_or_b32 %0, %0, 3, %8\n\t"
             "v_lshl_or_b32 %1, %1, 3, %8\n\t"
             "v_lshl_or_b32 %2, %2, 3, %8\n\t"
@@ -3442,130 +469,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_lshl_or_b32 %5, %5, 3, %8\n\t"
             "v_lshl_or_b32 %6, %6, 3, %8\n\t"
             "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
-            "v_lshl_or_b32 %0, %0, 3, %8\n\t"
-            "v_lshl_or_b32 %1, %1, 3, %8\n\t"
-            "v_lshl_or_b32 %2, %2, 3, %8\n\t"
-            "v_lshl_or_b32 %3, %3, 3, %8\n\t"
-            "v_lshl_or_b32 %4, %4, 3, %8\n\t"
-            "v_lshl_or_b32 %5, %5, 3, %8\n\t"
-            "v_lshl_or_b32 %6, %6, 3, %8\n\t"
-            "v_lshl_or_b32 %7, %7, 3, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LSHL_ADD) {
-            asm volatile(
+            asm volatile(REP16(
             "v_lshl_add_u32 %0, %0, 3, %8\n\t"
             "v_lshl_add_u32 %1, %1, 3, %8\n\t"
             "v_lshl_add_u32 %2, %2, 3, %8\n\t"
@@ -3574,130 +482,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_lshl_add_u32 %5, %5, 3, %8\n\t"
             "v_lshl_add_u32 %6, %6, 3, %8\n\t"
             "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u32 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u32 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u32 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u32 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u32 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u32 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u32 %7, %7, 3, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == AND_OR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_and_or_b32 %0, %0, %8, %9\n\t"
             "v_and_or_b32 %1, %1, %8, %9\n\t"
             "v_and_or_b32 %2, %2, %8, %9\n\t"
@@ -3706,130 +495,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_and_or_b32 %5, %5, %8, %9\n\t"
             "v_and_or_b32 %6, %6, %8, %9\n\t"
             "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
-            "v_and_or_b32 %0, %0, %8, %9\n\t"
-            "v_and_or_b32 %1, %1, %8, %9\n\t"
-            "v_and_or_b32 %2, %2, %8, %9\n\t"
-            "v_and_or_b32 %3, %3, %8, %9\n\t"
-            "v_and_or_b32 %4, %4, %8, %9\n\t"
-            "v_and_or_b32 %5, %5, %8, %9\n\t"
-            "v_and_or_b32 %6, %6, %8, %9\n\t"
-            "v_and_or_b32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ADD3) {
-            asm volatile(
+            asm volatile(REP16(
             "v_add3_u32 %0, %0, %8, %9\n\t"
             "v_add3_u32 %1, %1, %8, %9\n\t"
             "v_add3_u32 %2, %2, %8, %9\n\t"
@@ -3838,130 +508,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_add3_u32 %5, %5, %8, %9\n\t"
             "v_add3_u32 %6, %6, %8, %9\n\t"
             "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
-            "v_add3_u32 %0, %0, %8, %9\n\t"
-            "v_add3_u32 %1, %1, %8, %9\n\t"
-            "v_add3_u32 %2, %2, %8, %9\n\t"
-            "v_add3_u32 %3, %3, %8, %9\n\t"
-            "v_add3_u32 %4, %4, %8, %9\n\t"
-            "v_add3_u32 %5, %5, %8, %9\n\t"
-            "v_add3_u32 %6, %6, %8, %9\n\t"
-            "v_add3_u32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == BFE) {
-            asm volatile(
+            asm volatile(REP16(
             "v_bfe_u32 %0, %0, 8, 8\n\t"
             "v_bfe_u32 %1, %1, 8, 8\n\t"
             "v_bfe_u32 %2, %2, 8, 8\n\t"
@@ -3970,130 +521,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_bfe_u32 %5, %5, 8, 8\n\t"
             "v_bfe_u32 %6, %6, 8, 8\n\t"
             "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
-            "v_bfe_u32 %0, %0, 8, 8\n\t"
-            "v_bfe_u32 %1, %1, 8, 8\n\t"
-            "v_bfe_u32 %2, %2, 8, 8\n\t"
-            "v_bfe_u32 %3, %3, 8, 8\n\t"
-            "v_bfe_u32 %4, %4, 8, 8\n\t"
-            "v_bfe_u32 %5, %5, 8, 8\n\t"
-            "v_bfe_u32 %6, %6, 8, 8\n\t"
-            "v_bfe_u32 %7, %7, 8, 8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == BFI) {
-            asm volatile(
+            asm volatile(REP16(
             "v_bfi_b32 %0, %0, %8, %9\n\t"
             "v_bfi_b32 %1, %1, %8, %9\n\t"
             "v_bfi_b32 %2, %2, %8, %9\n\t"
@@ -4102,130 +534,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_bfi_b32 %5, %5, %8, %9\n\t"
             "v_bfi_b32 %6, %6, %8, %9\n\t"
             "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
-            "v_bfi_b32 %0, %0, %8, %9\n\t"
-            "v_bfi_b32 %1, %1, %8, %9\n\t"
-            "v_bfi_b32 %2, %2, %8, %9\n\t"
-            "v_bfi_b32 %3, %3, %8, %9\n\t"
-            "v_bfi_b32 %4, %4, %8, %9\n\t"
-            "v_bfi_b32 %5, %5, %8, %9\n\t"
-            "v_bfi_b32 %6, %6, %8, %9\n\t"
-            "v_bfi_b32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == PERM) {
-            asm volatile(
+            asm volatile(REP16(
             "v_perm_b32 %0, %0, %8, %9\n\t"
             "v_perm_b32 %1, %1, %8, %9\n\t"
             "v_perm_b32 %2, %2, %8, %9\n\t"
@@ -4234,130 +547,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_perm_b32 %5, %5, %8, %9\n\t"
             "v_perm_b32 %6, %6, %8, %9\n\t"
             "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
-            "v_perm_b32 %0, %0, %8, %9\n\t"
-            "v_perm_b32 %1, %1, %8, %9\n\t"
-            "v_perm_b32 %2, %2, %8, %9\n\t"
-            "v_perm_b32 %3, %3, %8, %9\n\t"
-            "v_perm_b32 %4, %4, %8, %9\n\t"
-            "v_perm_b32 %5, %5, %8, %9\n\t"
-            "v_perm_b32 %6, %6, %8, %9\n\t"
-            "v_perm_b32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(u), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ALIGNBIT) {
-            asm volatile(
+            asm volatile(REP16(
             "v_alignbit_b32 %0, %0, %8, 8\n\t"
             "v_alignbit_b32 %1, %1, %8, 8\n\t"
             "v_alignbit_b32 %2, %2, %8, 8\n\t"
@@ -4366,130 +560,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_alignbit_b32 %5, %5, %8, 8\n\t"
             "v_alignbit_b32 %6, %6, %8, 8\n\t"
             "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
-            "v_alignbit_b32 %0, %0, %8, 8\n\t"
-            "v_alignbit_b32 %1, %1, %8, 8\n\t"
-            "v_alignbit_b32 %2, %2, %8, 8\n\t"
-            "v_alignbit_b32 %3, %3, %8, 8\n\t"
-            "v_alignbit_b32 %4, %4, %8, 8\n\t"
-            "v_alignbit_b32 %5, %5, %8, 8\n\t"
-            "v_alignbit_b32 %6, %6, %8, 8\n\t"
-            "v_alignbit_b32 %7, %7, %8, 8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MUL_LO) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mul_lo_u32 %0, %0, %8\n\t"
             "v_mul_lo_u32 %1, %1, %8\n\t"
             "v_mul_lo_u32 %2, %2, %8\n\t"
@@ -4498,130 +573,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mul_lo_u32 %5, %5, %8\n\t"
             "v_mul_lo_u32 %6, %6, %8\n\t"
             "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
-            "v_mul_lo_u32 %0, %0, %8\n\t"
-            "v_mul_lo_u32 %1, %1, %8\n\t"
-            "v_mul_lo_u32 %2, %2, %8\n\t"
-            "v_mul_lo_u32 %3, %3, %8\n\t"
-            "v_mul_lo_u32 %4, %4, %8\n\t"
-            "v_mul_lo_u32 %5, %5, %8\n\t"
-            "v_mul_lo_u32 %6, %6, %8\n\t"
-            "v_mul_lo_u32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MIN_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_min_f32 %0, %0, %8\n\t"
             "v_min_f32 %1, %1, %8\n\t"
             "v_min_f32 %2, %2, %8\n\t"
@@ -4630,130 +586,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_min_f32 %5, %5, %8\n\t"
             "v_min_f32 %6, %6, %8\n\t"
             "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
-            "v_min_f32 %0, %0, %8\n\t"
-            "v_min_f32 %1, %1, %8\n\t"
-            "v_min_f32 %2, %2, %8\n\t"
-            "v_min_f32 %3, %3, %8\n\t"
-            "v_min_f32 %4, %4, %8\n\t"
-            "v_min_f32 %5, %5, %8\n\t"
-            "v_min_f32 %6, %6, %8\n\t"
-            "v_min_f32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MAX_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_max_f32 %0, %0, %9\n\t"
             "v_max_f32 %1, %1, %9\n\t"
             "v_max_f32 %2, %2, %9\n\t"
@@ -4762,130 +599,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_max_f32 %5, %5, %9\n\t"
             "v_max_f32 %6, %6, %9\n\t"
             "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_max_f32 %1, %1, %9\n\t"
-            "v_max_f32 %2, %2, %9\n\t"
-            "v_max_f32 %3, %3, %9\n\t"
-            "v_max_f32 %4, %4, %9\n\t"
-            "v_max_f32 %5, %5, %9\n\t"
-            "v_max_f32 %6, %6, %9\n\t"
-            "v_max_f32 %7, %7, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MIN_U32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_min_u32 %0, %0, %8\n\t"
             "v_min_u32 %1, %1, %8\n\t"
             "v_min_u32 %2, %2, %8\n\t"
@@ -4894,130 +612,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_min_u32 %5, %5, %8\n\t"
             "v_min_u32 %6, %6, %8\n\t"
             "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
-            "v_min_u32 %0, %0, %8\n\t"
-            "v_min_u32 %1, %1, %8\n\t"
-            "v_min_u32 %2, %2, %8\n\t"
-            "v_min_u32 %3, %3, %8\n\t"
-            "v_min_u32 %4, %4, %8\n\t"
-            "v_min_u32 %5, %5, %8\n\t"
-            "v_min_u32 %6, %6, %8\n\t"
-            "v_min_u32 %7, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MAX3) {
-            asm volatile(
+            asm volatile(REP16(
             "v_max3_f32 %0, %0, %8, %9\n\t"
             "v_max3_f32 %1, %1, %8, %9\n\t"
             "v_max3_f32 %2, %2, %8, %9\n\t"
@@ -5026,130 +625,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_max3_f32 %5, %5, %8, %9\n\t"
             "v_max3_f32 %6, %6, %8, %9\n\t"
             "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %1, %1, %8, %9\n\t"
-            "v_max3_f32 %2, %2, %8, %9\n\t"
-            "v_max3_f32 %3, %3, %8, %9\n\t"
-            "v_max3_f32 %4, %4, %8, %9\n\t"
-            "v_max3_f32 %5, %5, %8, %9\n\t"
-            "v_max3_f32 %6, %6, %8, %9\n\t"
-            "v_max3_f32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MED3) {
-            asm volatile(
+            asm volatile(REP16(
             "v_med3_f32 %0, %0, %8, %9\n\t"
             "v_med3_f32 %1, %1, %8, %9\n\t"
             "v_med3_f32 %2, %2, %8, %9\n\t"
@@ -5158,130 +638,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_med3_f32 %5, %5, %8, %9\n\t"
             "v_med3_f32 %6, %6, %8, %9\n\t"
             "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
-            "v_med3_f32 %0, %0, %8, %9\n\t"
-            "v_med3_f32 %1, %1, %8, %9\n\t"
-            "v_med3_f32 %2, %2, %8, %9\n\t"
-            "v_med3_f32 %3, %3, %8, %9\n\t"
-            "v_med3_f32 %4, %4, %8, %9\n\t"
-            "v_med3_f32 %5, %5, %8, %9\n\t"
-            "v_med3_f32 %6, %6, %8, %9\n\t"
-            "v_med3_f32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_UBYTE) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f32_ubyte1 %0, %8\n\t"
             "v_cvt_f32_ubyte1 %1, %8\n\t"
             "v_cvt_f32_ubyte1 %2, %8\n\t"
@@ -5290,130 +651,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f32_ubyte1 %5, %8\n\t"
             "v_cvt_f32_ubyte1 %6, %8\n\t"
             "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
-            "v_cvt_f32_ubyte1 %0, %8\n\t"
-            "v_cvt_f32_ubyte1 %1, %8\n\t"
-            "v_cvt_f32_ubyte1 %2, %8\n\t"
-            "v_cvt_f32_ubyte1 %3, %8\n\t"
-            "v_cvt_f32_ubyte1 %4, %8\n\t"
-            "v_cvt_f32_ubyte1 %5, %8\n\t"
-            "v_cvt_f32_ubyte1 %6, %8\n\t"
-            "v_cvt_f32_ubyte1 %7, %8\n\t"
+            )
               : ACC8 : "v"(u), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_F32_U32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f32_u32 %0, %0\n\t"
             "v_cvt_f32_u32 %1, %1\n\t"
             "v_cvt_f32_u32 %2, %2\n\t"
@@ -5422,130 +664,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f32_u32 %5, %5\n\t"
             "v_cvt_f32_u32 %6, %6\n\t"
             "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
-            "v_cvt_f32_u32 %0, %0\n\t"
-            "v_cvt_f32_u32 %1, %1\n\t"
-            "v_cvt_f32_u32 %2, %2\n\t"
-            "v_cvt_f32_u32 %3, %3\n\t"
-            "v_cvt_f32_u32 %4, %4\n\t"
-            "v_cvt_f32_u32 %5, %5\n\t"
-            "v_cvt_f32_u32 %6, %6\n\t"
-            "v_cvt_f32_u32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_U32_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_u32_f32 %0, %0\n\t"
             "v_cvt_u32_f32 %1, %1\n\t"
             "v_cvt_u32_f32 %2, %2\n\t"
@@ -5554,130 +677,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_u32_f32 %5, %5\n\t"
             "v_cvt_u32_f32 %6, %6\n\t"
             "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
-            "v_cvt_u32_f32 %0, %0\n\t"
-            "v_cvt_u32_f32 %1, %1\n\t"
-            "v_cvt_u32_f32 %2, %2\n\t"
-            "v_cvt_u32_f32 %3, %3\n\t"
-            "v_cvt_u32_f32 %4, %4\n\t"
-            "v_cvt_u32_f32 %5, %5\n\t"
-            "v_cvt_u32_f32 %6, %6\n\t"
-            "v_cvt_u32_f32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_F32_F16) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f32_f16 %0, %8\n\t"
             "v_cvt_f32_f16 %1, %8\n\t"
             "v_cvt_f32_f16 %2, %8\n\t"
@@ -5686,130 +690,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f32_f16 %5, %8\n\t"
             "v_cvt_f32_f16 %6, %8\n\t"
             "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
-            "v_cvt_f32_f16 %0, %8\n\t"
-            "v_cvt_f32_f16 %1, %8\n\t"
-            "v_cvt_f32_f16 %2, %8\n\t"
-            "v_cvt_f32_f16 %3, %8\n\t"
-            "v_cvt_f32_f16 %4, %8\n\t"
-            "v_cvt_f32_f16 %5, %8\n\t"
-            "v_cvt_f32_f16 %6, %8\n\t"
-            "v_cvt_f32_f16 %7, %8\n\t"
+            )
               : ACC8 : "v"(u), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_F16_F32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f16_f32 %0, %8\n\t"
             "v_cvt_f16_f32 %1, %8\n\t"
             "v_cvt_f16_f32 %2, %8\n\t"
@@ -5818,130 +703,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f16_f32 %5, %8\n\t"
             "v_cvt_f16_f32 %6, %8\n\t"
             "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
-            "v_cvt_f16_f32 %0, %8\n\t"
-            "v_cvt_f16_f32 %1, %8\n\t"
-            "v_cvt_f16_f32 %2, %8\n\t"
-            "v_cvt_f16_f32 %3, %8\n\t"
-            "v_cvt_f16_f32 %4, %8\n\t"
-            "v_cvt_f16_f32 %5, %8\n\t"
-            "v_cvt_f16_f32 %6, %8\n\t"
-            "v_cvt_f16_f32 %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == FLOOR) {
-            asm volatile(
+            asm volatile(REP16(
             "v_floor_f32 %0, %0\n\t"
             "v_floor_f32 %1, %1\n\t"
             "v_floor_f32 %2, %2\n\t"
@@ -5950,130 +716,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_floor_f32 %5, %5\n\t"
             "v_floor_f32 %6, %6\n\t"
             "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
-            "v_floor_f32 %0, %0\n\t"
-            "v_floor_f32 %1, %1\n\t"
-            "v_floor_f32 %2, %2\n\t"
-            "v_floor_f32 %3, %3\n\t"
-            "v_floor_f32 %4, %4\n\t"
-            "v_floor_f32 %5, %5\n\t"
-            "v_floor_f32 %6, %6\n\t"
-            "v_floor_f32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LDEXP) {
-            asm volatile(
+            asm volatile(REP16(
             "v_ldexp_f32 %0, %0, 1\n\t"
             "v_ldexp_f32 %1, %1, 1\n\t"
             "v_ldexp_f32 %2, %2, 1\n\t"
@@ -6082,130 +729,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_ldexp_f32 %5, %5, 1\n\t"
             "v_ldexp_f32 %6, %6, 1\n\t"
             "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
-            "v_ldexp_f32 %0, %0, 1\n\t"
-            "v_ldexp_f32 %1, %1, 1\n\t"
-            "v_ldexp_f32 %2, %2, 1\n\t"
-            "v_ldexp_f32 %3, %3, 1\n\t"
-            "v_ldexp_f32 %4, %4, 1\n\t"
-            "v_ldexp_f32 %5, %5, 1\n\t"
-            "v_ldexp_f32 %6, %6, 1\n\t"
-            "v_ldexp_f32 %7, %7, 1\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == RCP) {
-            asm volatile(
+            asm volatile(REP16(
             "v_rcp_f32 %0, %0\n\t"
             "v_rcp_f32 %1, %1\n\t"
             "v_rcp_f32 %2, %2\n\t"
@@ -6214,130 +742,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_rcp_f32 %5, %5\n\t"
             "v_rcp_f32 %6, %6\n\t"
             "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
-            "v_rcp_f32 %0, %0\n\t"
-            "v_rcp_f32 %1, %1\n\t"
-            "v_rcp_f32 %2, %2\n\t"
-            "v_rcp_f32 %3, %3\n\t"
-            "v_rcp_f32 %4, %4\n\t"
-            "v_rcp_f32 %5, %5\n\t"
-            "v_rcp_f32 %6, %6\n\t"
-            "v_rcp_f32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == SQRT) {
-            asm volatile(
+            asm volatile(REP16(
             "v_sqrt_f32 %0, %0\n\t"
             "v_sqrt_f32 %1, %1\n\t"
             "v_sqrt_f32 %2, %2\n\t"
@@ -6346,130 +755,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_sqrt_f32 %5, %5\n\t"
             "v_sqrt_f32 %6, %6\n\t"
             "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
-            "v_sqrt_f32 %0, %0\n\t"
-            "v_sqrt_f32 %1, %1\n\t"
-            "v_sqrt_f32 %2, %2\n\t"
-            "v_sqrt_f32 %3, %3\n\t"
-            "v_sqrt_f32 %4, %4\n\t"
-            "v_sqrt_f32 %5, %5\n\t"
-            "v_sqrt_f32 %6, %6\n\t"
-            "v_sqrt_f32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == RSQ) {
-            asm volatile(
+            asm volatile(REP16(
             "v_rsq_f32 %0, %0\n\t"
             "v_rsq_f32 %1, %1\n\t"
             "v_rsq_f32 %2, %2\n\t"
@@ -6478,130 +768,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_rsq_f32 %5, %5\n\t"
             "v_rsq_f32 %6, %6\n\t"
             "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
-            "v_rsq_f32 %0, %0\n\t"
-            "v_rsq_f32 %1, %1\n\t"
-            "v_rsq_f32 %2, %2\n\t"
-            "v_rsq_f32 %3, %3\n\t"
-            "v_rsq_f32 %4, %4\n\t"
-            "v_rsq_f32 %5, %5\n\t"
-            "v_rsq_f32 %6, %6\n\t"
-            "v_rsq_f32 %7, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == DIV_SCALE) {
-            asm volatile(
+            asm volatile(REP16(
             "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
             "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
             "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
@@ -6610,126 +781,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
             "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
             "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
-            "v_div_scale_f32 %0, vcc, %0, %8, %0\n\t"
-            "v_div_scale_f32 %1, vcc, %1, %8, %1\n\t"
-            "v_div_scale_f32 %2, vcc, %2, %8, %2\n\t"
-            "v_div_scale_f32 %3, vcc, %3, %8, %3\n\t"
-            "v_div_scale_f32 %4, vcc, %4, %8, %4\n\t"
-            "v_div_scale_f32 %5, vcc, %5, %8, %5\n\t"
-            "v_div_scale_f32 %6, vcc, %6, %8, %6\n\t"
-            "v_div_scale_f32 %7, vcc, %7, %8, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == DIV_FMAS) {
@@ -6866,7 +918,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == DIV_FIXUP) {
-            asm volatile(
+            asm volatile(REP16(
             "v_div_fixup_f32 %0, %0, %8, %9\n\t"
             "v_div_fixup_f32 %1, %1, %8, %9\n\t"
             "v_div_fixup_f32 %2, %2, %8, %9\n\t"
@@ -6875,130 +927,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_div_fixup_f32 %5, %5, %8, %9\n\t"
             "v_div_fixup_f32 %6, %6, %8, %9\n\t"
             "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-            "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-            "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-            "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-            "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-            "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-            "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-            "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-            "v_div_fixup_f32 %7, %7, %8, %9\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CMP_E64) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
@@ -7007,130 +940,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CMP_E32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
             "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
             "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
@@ -7139,130 +953,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
             "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
             "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CMP_U32_E64) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
             "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
             "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
@@ -7271,258 +966,13 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
             "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
             "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t"
-            "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CMPX) {
-            asm volatile(
+            asm volatile(REP128(
             "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
-            "v_cmpx_le_f32_e64 s[20:21], %8, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CNDMASK_E64) {
@@ -7925,7 +1375,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == PAIR_E32) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
@@ -7934,130 +1384,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == PAIR_E64) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
@@ -8066,130 +1397,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CMP_4SEL_E64) {
-            asm volatile(
+            asm volatile(REP4(
             "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\t"
@@ -8198,34 +1410,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\t"
             "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %0, %8\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %1, %8\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %2, %8\n\tv_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %9, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %3, %8\n\tv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\tv_cndmask_b32_e64 %4, %4, %9, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %4, %8\n\tv_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %9, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %5, %8\n\tv_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %9, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %6, %8\n\tv_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %9, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\t"
-            "v_cmp_lt_f32_e64 s[20:21], %7, %8\n\tv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %9, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %9, s[20:21]\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "s20", "s21");
         }
         else if (OP == CMP_4SEL_VCC) {
-            asm volatile(
+            asm volatile(REP4(
             "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\t"
@@ -8234,30 +1423,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
             "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %0, %8\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %1, %8\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %2, %8\n\tv_cndmask_b32_e32 %2, %2, %8, vcc\n\tv_cndmask_b32_e32 %3, %3, %9, vcc\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %3, %8\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %4, %8\n\tv_cndmask_b32_e32 %4, %4, %8, vcc\n\tv_cndmask_b32_e32 %5, %5, %9, vcc\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %5, %8\n\tv_cndmask_b32_e32 %5, %5, %8, vcc\n\tv_cndmask_b32_e32 %6, %6, %9, vcc\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %6, %8\n\tv_cndmask_b32_e32 %6, %6, %8, vcc\n\tv_cndmask_b32_e32 %7, %7, %9, vcc\n\tv_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
-            "v_cmp_lt_f32_e32 vcc, %7, %8\n\tv_cndmask_b32_e32 %7, %7, %8, vcc\n\tv_cndmask_b32_e32 %0, %0, %9, vcc\n\tv_cndmask_b32_e32 %1, %1, %8, vcc\n\tv_cndmask_b32_e32 %2, %2, %9, vcc\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc");
         }
         else if (OP == EXEC_MOV) {
@@ -8297,7 +1463,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
               : ACC8 : "v"(b), "v"(c) : "s20", "s21", "s22", "s23");
         }
         else if (OP == SWAP) {
-            asm volatile(
+            asm volatile(REP16(
             "v_swap_b32 %0, %1\n\t"
             "v_swap_b32 %1, %2\n\t"
             "v_swap_b32 %2, %3\n\t"
@@ -8306,130 +1472,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_swap_b32 %5, %6\n\t"
             "v_swap_b32 %6, %7\n\t"
             "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
-            "v_swap_b32 %0, %1\n\t"
-            "v_swap_b32 %1, %2\n\t"
-            "v_swap_b32 %2, %3\n\t"
-            "v_swap_b32 %3, %4\n\t"
-            "v_swap_b32 %4, %5\n\t"
-            "v_swap_b32 %5, %6\n\t"
-            "v_swap_b32 %6, %7\n\t"
-            "v_swap_b32 %7, %0\n\t"
+            )
               : ACC8 : "v"(b), "v"(c));
         }
         else if (OP == READFIRSTLANE) {
-            asm volatile(
+            asm volatile(REP16(
             "v_readfirstlane_b32 s22, %0\n\t"
             "v_readfirstlane_b32 s22, %1\n\t"
             "v_readfirstlane_b32 s22, %2\n\t"
@@ -8438,130 +1485,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_readfirstlane_b32 s22, %5\n\t"
             "v_readfirstlane_b32 s22, %6\n\t"
             "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
-            "v_readfirstlane_b32 s22, %0\n\t"
-            "v_readfirstlane_b32 s22, %1\n\t"
-            "v_readfirstlane_b32 s22, %2\n\t"
-            "v_readfirstlane_b32 s22, %3\n\t"
-            "v_readfirstlane_b32 s22, %4\n\t"
-            "v_readfirstlane_b32 s22, %5\n\t"
-            "v_readfirstlane_b32 s22, %6\n\t"
-            "v_readfirstlane_b32 s22, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MBCNT) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
             "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
             "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
@@ -8570,130 +1498,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
             "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
             "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
-            "v_mbcnt_lo_u32_b32 %0, -1, %0\n\t"
-            "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t"
-            "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t"
-            "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t"
-            "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t"
-            "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t"
-            "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t"
-            "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MOV_DPP) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -8702,130 +1511,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MOV_SDWA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
             "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
             "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
@@ -8834,130 +1524,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
             "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
             "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %1, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %2, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %3, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %4, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %5, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %6, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
-            "v_mov_b32_sdwa %7, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == OR_SDWA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
             "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
             "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
@@ -8966,130 +1537,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
             "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
             "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-            "v_or_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == ADD_F32_SDWA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
             "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
             "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
@@ -9098,130 +1550,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
             "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
             "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-            "v_add_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_F32_F16_SDWA) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
             "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
             "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
@@ -9230,130 +1563,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
             "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
             "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == CVT_UBYTE3) {
-            asm volatile(
+            asm volatile(REP16(
             "v_cvt_f32_ubyte3 %0, %8\n\t"
             "v_cvt_f32_ubyte3 %1, %8\n\t"
             "v_cvt_f32_ubyte3 %2, %8\n\t"
@@ -9362,130 +1576,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_cvt_f32_ubyte3 %5, %8\n\t"
             "v_cvt_f32_ubyte3 %6, %8\n\t"
             "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
-            "v_cvt_f32_ubyte3 %0, %8\n\t"
-            "v_cvt_f32_ubyte3 %1, %8\n\t"
-            "v_cvt_f32_ubyte3 %2, %8\n\t"
-            "v_cvt_f32_ubyte3 %3, %8\n\t"
-            "v_cvt_f32_ubyte3 %4, %8\n\t"
-            "v_cvt_f32_ubyte3 %5, %8\n\t"
-            "v_cvt_f32_ubyte3 %6, %8\n\t"
-            "v_cvt_f32_ubyte3 %7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MUL_F32_ABS) {
-            asm volatile(
+            asm volatile(REP16(
             "v_mul_f32_e64 %0, |%0|, %8\n\t"
             "v_mul_f32_e64 %1, |%1|, %8\n\t"
             "v_mul_f32_e64 %2, |%2|, %8\n\t"
@@ -9494,130 +1589,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_mul_f32_e64 %5, |%5|, %8\n\t"
             "v_mul_f32_e64 %6, |%6|, %8\n\t"
             "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
-            "v_mul_f32_e64 %0, |%0|, %8\n\t"
-            "v_mul_f32_e64 %1, |%1|, %8\n\t"
-            "v_mul_f32_e64 %2, |%2|, %8\n\t"
-            "v_mul_f32_e64 %3, |%3|, %8\n\t"
-            "v_mul_f32_e64 %4, |%4|, %8\n\t"
-            "v_mul_f32_e64 %5, |%5|, %8\n\t"
-            "v_mul_f32_e64 %6, |%6|, %8\n\t"
-            "v_mul_f32_e64 %7, |%7|, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MAX_F32_E64) {
-            asm volatile(
+            asm volatile(REP16(
             "v_max_f32_e64 %0, -%0, %8\n\t"
             "v_max_f32_e64 %1, -%1, %8\n\t"
             "v_max_f32_e64 %2, -%2, %8\n\t"
@@ -9626,130 +1602,11 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_max_f32_e64 %5, -%5, %8\n\t"
             "v_max_f32_e64 %6, -%6, %8\n\t"
             "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
-            "v_max_f32_e64 %0, -%0, %8\n\t"
-            "v_max_f32_e64 %1, -%1, %8\n\t"
-            "v_max_f32_e64 %2, -%2, %8\n\t"
-            "v_max_f32_e64 %3, -%3, %8\n\t"
-            "v_max_f32_e64 %4, -%4, %8\n\t"
-            "v_max_f32_e64 %5, -%5, %8\n\t"
-            "v_max_f32_e64 %6, -%6, %8\n\t"
-            "v_max_f32_e64 %7, -%7, %8\n\t"
+            )
               : ACC8 : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == LSHL_ADD_U64) {
-            asm volatile(
+            asm volatile(REP16(
             "v_lshl_add_u64 %0, %0, 3, %8\n\t"
             "v_lshl_add_u64 %1, %1, 3, %8\n\t"
             "v_lshl_add_u64 %2, %2, 3, %8\n\t"
@@ -9758,126 +1615,7 @@ __global__ void __launch_bounds__(1024) k_calib(uint32_t iters, float seed, unsi
             "v_lshl_add_u64 %5, %5, 3, %8\n\t"
             "v_lshl_add_u64 %6, %6, 3, %8\n\t"
             "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
-            "v_lshl_add_u64 %0, %0, 3, %8\n\t"
-            "v_lshl_add_u64 %1, %1, 3, %8\n\t"
-            "v_lshl_add_u64 %2, %2, 3, %8\n\t"
-            "v_lshl_add_u64 %3, %3, 3, %8\n\t"
-            "v_lshl_add_u64 %4, %4, 3, %8\n\t"
-            "v_lshl_add_u64 %5, %5, 3, %8\n\t"
-            "v_lshl_add_u64 %6, %6, 3, %8\n\t"
-            "v_lshl_add_u64 %7, %7, 3, %8\n\t"
+            )
               : PACC8 : "v"(pb), "v"(pc) : "vcc", "s20", "s21", "s22");
         }
         else if (OP == MIX_TRAV) {
