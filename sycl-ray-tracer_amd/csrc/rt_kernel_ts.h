@@ -382,9 +382,9 @@ __global__ void __launch_bounds__(kTsBlock, RT_TS_OCC) k_megakernel_ts(SceneDev 
             if (lane == 0 && n_retired) (void)__hip_atomic_fetch_sub(live_slots, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (STATS) c_rounds++, c_cycles += (unsigned long long)((long long)__builtin_readcyclecounter() - t_round);
         }
-        const uint32_t total = wave_sum_u32(rays);
-        if (STATS && lane == 0) atomicAdd(stats_out + 4, c_rounds), atomicAdd(stats_out + 5, (unsigned long long)total), atomicAdd(stats_out + 14, c_cycles);
-        if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
+        const unsigned long long total = wave_sum_u64(rays);
+        if (STATS && lane == 0) atomicAdd(stats_out + 4, c_rounds), atomicAdd(stats_out + 5, total), atomicAdd(stats_out + 14, c_cycles);
+        if (lane == 0 && total) atomicAdd(ray_counter, total);
         if (lane == 0 && failed()) atomicAdd(ray_counter + 5, 1ull); // error word: the host turns it into RT_ERR_HIP
     }
     if (STATS && lane == 0 && wave < kTsTWaves) {

@@ -84,6 +84,11 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v; // valid in lane 0
 }
+// the same without overflow: a lane's ray count may be anything below 2^32 (spp x depth is bounded at 2^26 per pixel, a lane renders
+// many pixels), so the halves are summed separately
+RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
+    return (unsigned long long)wave_sum_u32(v & 0xFFFFu) + ((unsigned long long)wave_sum_u32(v >> 16) << 16);
+}
 
 // ---- K1: megakernel ---------------------------------------------------------------------------------
 // One lane per pixel; a 64-thread block is one wave covering an 8x8 pixel tile. The sample loop, the
@@ -313,8 +318,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         __builtin_amdgcn_s_setprio(1);
 #endif
     }
-    const uint32_t total = wave_sum_u32(rays);
-    if (lane == 0 && total) atomicAdd(ray_counter, (unsigned long long)total);
+    const unsigned long long total = wave_sum_u64(rays);
+    if (lane == 0 && total) atomicAdd(ray_counter, total);
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
@@ -916,8 +921,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         __builtin_amdgcn_s_setprio(2);
 #endif
     }
-    const uint32_t total = wave_sum_u32(rays);
-    if (lane == 0 && total) atomicAdd(extra_rays, (unsigned long long)total);
+    const unsigned long long total = wave_sum_u64(rays);
+    if (lane == 0 && total) atomicAdd(extra_rays, total);
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
