@@ -5,7 +5,10 @@
 //   k_wf_generate  == K3, generate_camera_rays               (src/render_wavefront.cpp:106-124)
 //   k_wf_extend    == K4a, the rtcIntersect1 half of shoot_rays (src/render_wavefront.cpp:244-273)
 //   k_wf_shade     == K4b + K5, shading/compaction half of shoot_rays + merge_samples (:273-312,340-354)
+//   k_wf_finish    == K4 + K5 for every bounce of a path (and, by default, K3 for every sample after a pixel's first): the
+//                     WavefrontRenderer's default schedule, one launch per frame (:222-354, 396-417)
 //   k_wf_resolve   == K6 convert_image_to_srgb + K7 write_image (:377-390, src/util.hpp:16-23)
+//   (rt_kernel_ts.h: k_megakernel_ts, an experiment)
 #pragma once
 #include "rt_device.h"
 
