@@ -109,6 +109,18 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #ifndef RT_MEGA_REFILL
 #define RT_MEGA_REFILL 1u // idle lanes that trigger a pixel fetch (re-tuned with whole-leaf steps: 8 -> 1, +2 %)
 #endif
+// ... for pixels of many samples. A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few
+// lanes take part; with few samples per pixel lanes fall idle all the time and it pays to let some gather first. Measured, atrium
+// 1080p, Mrays/s with thresholds 1 / 2 / 4 / 8 / 16: 4 spp 5580 / 6612 / 6749 / 6618 / 6361 (8K: 5529 -> 7719 at 8), 16 spp 7086 /
+// 7071 / 7035 / 6871 / 6466, 64 spp 7241 / 7199 / 7153 / 6977 / 6747.
+#ifndef RT_MEGA_REFILL_BY_SPP
+#define RT_MEGA_REFILL_BY_SPP 1
+#endif
+#if RT_MEGA_REFILL_BY_SPP
+#define RT_REFILL_FOR(SPP) ((SPP) <= 5u ? 4u : (SPP) <= 10u ? 2u : RT_MEGA_REFILL)
+#else
+#define RT_REFILL_FOR(SPP) RT_MEGA_REFILL
+#endif
 #ifndef RT_MEGA_SHADE_PCT
 #define RT_MEGA_SHADE_PCT 80u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %)
 #endif
@@ -234,7 +246,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 take = quota > n_now ? (quota - n_now < cnt ? quota - n_now : cnt) : 0u;
             }
 #endif
-            if (cnt >= RT_MEGA_REFILL && take) {
+            if (cnt >= RT_REFILL_FOR(spp) && take) {
                 // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
@@ -776,7 +788,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         if (!(REQ ? drained : exhausted)) {
             const unsigned long long idle_m = __ballot(!live && !waiting);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            if (cnt >= RT_MEGA_REFILL) {
+            if (cnt >= (!REQ && n_samples > 1u ? RT_REFILL_FOR(n_samples) : RT_MEGA_REFILL)) {
                 if (chunk_pos == chunk_end) {
                     if (!exhausted) {
                         // A slot is a whole pixel-chain when the lane keeps its pixel for several samples: then a wave takes exactly as
