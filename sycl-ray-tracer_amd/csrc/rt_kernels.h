@@ -109,18 +109,43 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #ifndef RT_MEGA_REFILL
 #define RT_MEGA_REFILL 1u // idle lanes that trigger a pixel fetch (re-tuned with whole-leaf steps: 8 -> 1, +2 %)
 #endif
-// ... for pixels of many samples. A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few
-// lanes take part; with few samples per pixel lanes fall idle all the time and it pays to let some gather first. Measured, atrium
-// 1080p, Mrays/s with thresholds 1 / 2 / 4 / 8 / 16: 4 spp 5580 / 6612 / 6749 / 6618 / 6361 (8K: 5529 -> 7719 at 8), 16 spp 7086 /
-// 7071 / 7035 / 6871 / 6466, 64 spp 7241 / 7199 / 7153 / 6977 / 6747.
-#ifndef RT_MEGA_REFILL_BY_SPP
-#define RT_MEGA_REFILL_BY_SPP 1
+// ... as the STARTING value. A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
+// part, and a lane that waits for company is idle: with lanes falling idle at a rate L per unit of wave time, refilling at T idle lanes
+// costs 64 * C * L / T + T / 2 lane-times per unit time (C: the wave time of a refill), least at T = sqrt(128 * C * L). L depends on the
+// workload — a pixel lives 64 spp x 8 rays x 26 steps on the atrium, 16 spp x 1.2 rays x 3 steps on the cube — so every wave estimates
+// it: pixels its lanes finished in the last 32 shading rounds, over the wave time of those rounds in units of one traversal step
+// (steps taken + 5 per shading round), C = 2.5 steps: T^2 = 320 * ended / (160 + steps), T in 1 ... 16, by a chain of scalar compares
+// (no clock, no float: a version with s_memtime and a float square root cost the atrium 2.5 %, the estimate from ended pixels alone
+// 1-2 %). Measured with fixed thresholds 1 / 4 / 8, Mrays/s: atrium 1080p 64 spp 7241 / 7153 / 6977, 16 spp 7086 / 7035 / 6871, 4 spp
+// 5580 / 6749 / 6618; Cornell box 4K 16 spp 9192 / 18106 / 18018; cube 4K 16 spp 21636 / 39292 / 50509.
+#ifndef RT_MEGA_REFILL_ADAPTIVE
+#define RT_MEGA_REFILL_ADAPTIVE 1
 #endif
-#if RT_MEGA_REFILL_BY_SPP
-#define RT_REFILL_FOR(SPP) ((SPP) <= 5u ? 4u : (SPP) <= 10u ? 2u : RT_MEGA_REFILL)
+struct RefillPolicy { // wave-uniform
+    uint32_t threshold = RT_MEGA_REFILL, ended = 0, rounds = 0, steps = 0;
+    RT_DEV void stepped(uint32_t n) { // n traversal steps taken
+#if RT_MEGA_REFILL_ADAPTIVE
+        steps += n;
 #else
-#define RT_REFILL_FOR(SPP) RT_MEGA_REFILL
+        (void)n;
 #endif
+    }
+    // after every shading round, in wave-uniform control flow; `finished`: this lane has just finished its pixel (or, where queue slots
+    // are single paths, its path)
+    RT_DEV void round(bool finished) {
+#if RT_MEGA_REFILL_ADAPTIVE
+        ended += (uint32_t)__popcll(__ballot(finished));
+        if (++rounds == 32u) {
+            const uint32_t num = 320u * ended, den = 160u + steps;
+            threshold = num < 4u * den ? 1u : num < 9u * den ? 2u : num < 16u * den ? 3u : num < 25u * den ? 4u : num < 36u * den ? 5u
+                        : num < 64u * den ? 6u : num < 100u * den ? 8u : num < 144u * den ? 10u : num < 256u * den ? 12u : 16u;
+            ended = 0, rounds = 0, steps = 0;
+        }
+#else
+        (void)finished;
+#endif
+    }
+};
 #ifndef RT_MEGA_SHADE_PCT
 #define RT_MEGA_SHADE_PCT 80u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %)
 #endif
@@ -172,6 +197,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
+    RefillPolicy refill;    // idle lanes that trigger a pixel fetch: set per wave from the pixels it finishes
     bool exhausted = false; // wave-uniform: every region's cursor has passed its last slot
     // RT_MEGA_XCD_REGIONS=1 (round 1's default, now OFF): the frame's pixel slots cut into 8 contiguous regions, one per XCD — a wave
     // first drains the region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others, so that waves which share an L2 work
@@ -246,7 +272,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 take = quota > n_now ? (quota - n_now < cnt ? quota - n_now : cnt) : 0u;
             }
 #endif
-            if (cnt >= RT_REFILL_FOR(spp) && take) {
+            if (cnt >= refill.threshold && take) {
                 // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
@@ -275,6 +301,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
             if (STATS) ws.live_lane_steps += n_live;
+            refill.stepped(RT_MEGA_UNROLL);
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #if RT_MEGA_TAIL_UNROLL1
             if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
@@ -296,6 +323,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
 #elif RT_MEGA_PRIO == 2 || RT_MEGA_PRIO == 4 || RT_MEGA_PRIO == 5
         __builtin_amdgcn_s_setprio(0);
 #endif
+        bool pixel_finished = false;
         if (live && T.cur == kTravDone) {
             f3 res;
             rays++;
@@ -310,7 +338,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 if (s < spp) {
                     r = camera_ray(cam, x, gy, rng);
                 } else { // pixel finished: mean, sqrt gamma, fp32 + unorm8 stores (src/render_megakernel.cpp:154-158)
-                    live = false;
+                    live = false, pixel_finished = true;
                     const float n = (float)spp;
                     const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
                     const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
@@ -322,6 +350,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             }
             if (live) trav_begin(T, r.org, ray_dir(r), stack);
         }
+        refill.round(pixel_finished);
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
 #if RT_MEGA_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -753,6 +782,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     Trav T;
     T.cur = kTravDone;
     bool live = false;
+    RefillPolicy refill; // idle lanes that trigger a fetch of queue slots: set per wave from the pixels (or paths) it finishes
     RayState r{};
     uint32_t id = 0, rng = 0, depth = 0, rays = 0;
     uint32_t samples_left = 0;  // samples of this lane's pixel still to render in this launch, the current one included
@@ -788,7 +818,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         if (!(REQ ? drained : exhausted)) {
             const unsigned long long idle_m = __ballot(!live && !waiting);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            if (cnt >= (!REQ && n_samples > 1u ? RT_REFILL_FOR(n_samples) : RT_MEGA_REFILL)) {
+            if (cnt >= refill.threshold) {
                 if (chunk_pos == chunk_end) {
                     if (!exhausted) {
                         // A slot is a whole pixel-chain when the lane keeps its pixel for several samples: then a wave takes exactly as
@@ -868,6 +898,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             const bool done_trav = live && T.cur == kTravDone;
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
+            refill.stepped(RT_MEGA_UNROLL);
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
@@ -876,7 +907,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
 #if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        bool requeue = false;
+        bool requeue = false, slot_finished = false;
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
             if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum
             f3 res;
@@ -912,13 +943,14 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 ends = false;
             }
             if (ends) {
-                live = false;
+                live = false, slot_finished = true;
                 if (REQ) requeue = samples_left > 1u;
                 if (!requeue) rng_buf[id] = rng; // ScopedRng store (the next launch reads it; inside this launch the word travels in the entry)
             } else {
                 trav_begin(T, r.org, ray_dir(r), stack);
             }
         }
+        refill.round(slot_finished);
         if (REQ) {
             const unsigned long long rq_m = __ballot(requeue);
             const uint32_t n_rq = (uint32_t)__popcll(rq_m);
