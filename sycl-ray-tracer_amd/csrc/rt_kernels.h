@@ -106,6 +106,9 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 6
 #endif
+#ifndef RT_MEGA_UNROLL
+#define RT_MEGA_UNROLL 3 // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
+#endif
 #ifndef RT_MEGA_REFILL
 #define RT_MEGA_REFILL 1u // idle lanes that trigger a pixel fetch (re-tuned with whole-leaf steps: 8 -> 1, +2 %)
 #endif
@@ -121,25 +124,26 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #ifndef RT_MEGA_REFILL_ADAPTIVE
 #define RT_MEGA_REFILL_ADAPTIVE 1
 #endif
-struct RefillPolicy { // wave-uniform
-    uint32_t threshold = RT_MEGA_REFILL, ended = 0, rounds = 0, steps = 0;
-    RT_DEV void stepped(uint32_t n) { // n traversal steps taken
+struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at the SGPR limit: four words of state cost it 0.9 %):
+    // bits 0-4 shading rounds of the window, 5-16 pixels ended, 17-27 traversal iterations (RT_MEGA_UNROLL steps each), 28-31 threshold - 1
+    uint32_t w = (RT_MEGA_REFILL - 1u) << 28;
+    RT_DEV uint32_t threshold() const { return (w >> 28) + 1u; }
+    RT_DEV void stepped() { // one iteration of the traversal loop (RT_MEGA_UNROLL steps)
 #if RT_MEGA_REFILL_ADAPTIVE
-        steps += n;
-#else
-        (void)n;
+        w += 1u << 17;
 #endif
     }
     // after every shading round, in wave-uniform control flow; `finished`: this lane has just finished its pixel (or, where queue slots
     // are single paths, its path)
     RT_DEV void round(bool finished) {
 #if RT_MEGA_REFILL_ADAPTIVE
-        ended += (uint32_t)__popcll(__ballot(finished));
-        if (++rounds == 32u) {
+        w += ((uint32_t)__popcll(__ballot(finished)) << 5) + 1u;
+        if ((w & 31u) == 0u) { // 32 rounds
+            const uint32_t ended = (w >> 5) & 0xFFFu, steps = ((w >> 17) & 0x7FFu) * RT_MEGA_UNROLL;
             const uint32_t num = 320u * ended, den = 160u + steps;
-            threshold = num < 4u * den ? 1u : num < 9u * den ? 2u : num < 16u * den ? 3u : num < 25u * den ? 4u : num < 36u * den ? 5u
-                        : num < 64u * den ? 6u : num < 100u * den ? 8u : num < 144u * den ? 10u : num < 256u * den ? 12u : 16u;
-            ended = 0, rounds = 0, steps = 0;
+            const uint32_t t = num < 4u * den ? 1u : num < 9u * den ? 2u : num < 16u * den ? 3u : num < 25u * den ? 4u : num < 36u * den ? 5u
+                               : num < 64u * den ? 6u : num < 100u * den ? 8u : num < 144u * den ? 10u : num < 256u * den ? 12u : 16u;
+            w = (t - 1u) << 28;
         }
 #else
         (void)finished;
@@ -158,9 +162,6 @@ struct RefillPolicy { // wave-uniform
 #ifndef RT_MEGA_PRIO
 #define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
                        // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
-#endif
-#ifndef RT_MEGA_UNROLL
-#define RT_MEGA_UNROLL 3 // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
 #endif
 #ifndef RT_MEGA_GSS
 #define RT_MEGA_GSS 0 // guided self-scheduling of the pixel queue (see the refill step): measured, off
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 take = quota > n_now ? (quota - n_now < cnt ? quota - n_now : cnt) : 0u;
             }
 #endif
-            if (cnt >= refill.threshold && take) {
+            if (cnt >= refill.threshold() && take) {
                 // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
             if (STATS) ws.live_lane_steps += n_live;
-            refill.stepped(RT_MEGA_UNROLL);
+            refill.stepped();
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #if RT_MEGA_TAIL_UNROLL1
             if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
@@ -818,7 +819,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         if (!(REQ ? drained : exhausted)) {
             const unsigned long long idle_m = __ballot(!live && !waiting);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            if (cnt >= refill.threshold) {
+            if (cnt >= refill.threshold()) {
                 if (chunk_pos == chunk_end) {
                     if (!exhausted) {
                         // A slot is a whole pixel-chain when the lane keeps its pixel for several samples: then a wave takes exactly as
@@ -898,7 +899,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             const bool done_trav = live && T.cur == kTravDone;
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
-            refill.stepped(RT_MEGA_UNROLL);
+            refill.stepped();
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
