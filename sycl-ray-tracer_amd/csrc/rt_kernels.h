@@ -408,19 +408,58 @@ __global__ void __launch_bounds__(256) k_wf_init(const CameraDev* __restrict__ c
 // of the slots does not matter: 8x8-tile order instead of rows was measured at +-0.)
 __global__ void __launch_bounds__(256) k_wf_generate(const CameraDev* __restrict__ camp, TileDev tile, uint32_t n_local,
                                                       uint32_t* __restrict__ rng, QueueDev q,
-                                                      uint32_t* __restrict__ count_out, uint32_t spread) {
+                                                      uint32_t* __restrict__ count_out, uint32_t spread, const uint32_t* __restrict__ tile_order) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) *count_out = n_local; // "*ray_buffer_length = img_size.size()" (src/render_wavefront.cpp:104)
     if (i >= n_local) return;
     const CameraDev cam = *camp;
     const uint32_t nw = n_local >> 6;
-    const uint32_t id = spread && nw * 64u == n_local ? (i & 63u) * nw + (i >> 6) : i; // (a bijection only for tiles of whole chunks)
+    uint32_t id = spread && nw * 64u == n_local ? (i & 63u) * nw + (i >> 6) : i; // (a bijection only for tiles of whole chunks)
+    if (tile_order) { // cost-ordered second launch (k_wf_order_tiles): slots in 8x8 blocks, the most expensive block first
+        const uint32_t t = tile_order[i >> 6], w = i & 63u, tiles_x = (uint32_t)cam.width >> 3;
+        id = ((t / tiles_x) * 8u + (w >> 3)) * (uint32_t)cam.width + (t % tiles_x) * 8u + (w & 7u);
+    }
     const int x = (int)(id % (uint32_t)cam.width), ly = (int)(id / (uint32_t)cam.width);
     const int gy = tile_global_row(tile, ly);
     uint32_t st = rng[id];
     const RayState r = gy < cam.height ? camera_ray(cam, x, gy, st) : RayState{};
     rng[id] = st;
     queue_store(q, i, id, r);
+}
+
+// ---- longest chains first ------------------------------------------------------------------------------------------------
+// A frame of a few pixel generations (1/2, 1/4 of the 1080p frame on one GPU; the Cornell box at 1024x1024) ends when its last pixel
+// chain does, and in queue order the last chains to START are as long as any. Longest-processing-time-first needs the costs in
+// advance, and a pixel's first sample tells: the renderer traces sample 0 of every pixel in a launch of its own, which records the
+// length of every path (cost, one byte per pixel); the 8x8 blocks of the tile are then sorted by the rays their 64 first samples took
+// (k_wf_tile_cost + k_wf_order_tiles: one counting sort in one workgroup), and the launch for the remaining samples takes its pixels in
+// that order, the most expensive blocks first — so that what starts last is cheap. A pixel's samples are still traced one after the
+// other with one RNG word: the frame is unchanged.
+__global__ void __launch_bounds__(64) k_wf_tile_cost(const uint8_t* __restrict__ cost, uint32_t width, uint32_t n_tiles, uint32_t* __restrict__ key) {
+    const uint32_t t = blockIdx.x, w = threadIdx.x, tiles_x = width >> 3;
+    if (t >= n_tiles) return;
+    uint32_t v = cost[((t / tiles_x) * 8u + (w >> 3)) * width + (t % tiles_x) * 8u + (w & 7u)];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (w == 0) key[t] = v >> 2; // 0 ... 64 * 255 / 4
+}
+constexpr uint32_t kOrderBins = 64u * 255u / 4u + 1u;
+__global__ void __launch_bounds__(1024) k_wf_order_tiles(const uint32_t* __restrict__ key, uint32_t n_tiles, uint32_t* __restrict__ order) {
+    __shared__ uint32_t bin[kOrderBins];
+    for (uint32_t i = threadIdx.x; i < kOrderBins; i += 1024u) bin[i] = 0;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) atomicAdd(&bin[key[t] < kOrderBins ? key[t] : kOrderBins - 1u], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { // exclusive prefix from the most expensive bin down: bin[k] = first position of its tiles
+        uint32_t run = 0;
+        for (uint32_t k = kOrderBins; k-- > 0;) {
+            const uint32_t c = bin[k];
+            bin[k] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) order[atomicAdd(&bin[key[t] < kOrderBins ? key[t] : kOrderBins - 1u], 1u)] = t;
 }
 
 // ---- K4 is split in two kernels: EXTEND (closest hit) and SHADE (scatter + compaction) ---------------
@@ -759,7 +798,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
                                                                     unsigned long long* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
                                                                     uint32_t n_samples, uint32_t rr_start,
-                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots) {
+                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots, uint8_t* __restrict__ cost_out) {
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
@@ -943,6 +982,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 depth = 0, first_counted = false;
                 ends = false;
             }
+            if (ends && cost_out) cost_out[id] = (uint8_t)(depth < 255u ? depth : 255u); // rays of this path: what the cost ordering sorts by
             if (ends) {
                 live = false, slot_finished = true;
                 if (REQ) requeue = samples_left > 1u;

@@ -155,6 +155,12 @@ struct rt_renderer {
         unsigned long long* d_rq_entries = nullptr;
         uint32_t* d_rq_ctl = nullptr;
         uint32_t rq_capacity = 0;
+        // cost ordering of the one-launch schedule (k_wf_tile_cost / k_wf_order_tiles): rays of every pixel's first sample, the 8x8
+        // blocks' keys and their order
+        uint8_t* d_cost = nullptr;
+        uint32_t* d_tile_key = nullptr;
+        uint32_t* d_tile_order = nullptr;
+        uint32_t n_tiles = 0; // 0: no cost ordering for this tile
         std::vector<uint32_t> h_counts;
         unsigned long long* d_extra = nullptr; // per launch: rays k_wf_finish traced beyond its queue's length; [spp]: the dynamic queue's error word
         std::vector<unsigned long long> h_extra;
@@ -183,6 +189,7 @@ struct rt_renderer {
     uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
     uint32_t wf_samples_per_launch = RT_WF_SAMPLES_PER_LAUNCH_DEFAULT; // RT_WF_SAMPLES_PER_LAUNCH
     bool wf_streams_set = false, wf_requeue_set = false; // RT_WF_STREAMS / RT_WF_REQUEUE given: no automatic choice of the regime
+    bool wf_lpt = true;     // cost-ordered second launch of the one-launch schedule (RT_WF_LPT=0: off)
     bool wf_requeue = true; // with several samples per launch: breadth first through a device-wide dynamic queue (RT_WF_REQUEUE=0: the lane keeps its pixel)
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
     hipGraphExec_t graph_exec = nullptr;
@@ -224,7 +231,7 @@ void free_tile_buffers(rt_renderer* r) {
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
     fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
     for (auto& L : r->lanes) {
-        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra);
+        fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra), fr(L.d_cost), fr(L.d_tile_key), fr(L.d_tile_order);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
@@ -258,6 +265,10 @@ bool wf_one_launch(const rt_renderer* r) {
 // hands every wave pixels spread evenly over the tile
 bool wf_spread(const rt_renderer* r) { return wf_one_launch(r) && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u; }
 bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_one_launch(r); }
+// Longest chains first (rt_kernels.h, k_wf_order_tiles): in the one-launch schedule, for tiles of more than one pixel generation, sample 0
+// of every pixel is traced in a launch of its own and the launch for the other samples takes the 8x8 blocks in the order of what their
+// first samples cost. RT_WF_LPT=0 switches it off.
+bool wf_cost_order(const rt_renderer* r) { return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 4; }
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
 // camera ray on; with the dynamic queue bounded by the entry's 8-bit sample field and the queue's size (<= 1 GiB per stream lane)
@@ -330,6 +341,13 @@ int alloc_tile_buffers(rt_renderer* r) {
             L.h_extra.resize((size_t)r->spp + 1); // + the dynamic queue's error word
             HIPCHK(hipMalloc((void**)&L.d_extra, L.h_extra.size() * 8));
             const uint32_t chunk = wf_chunk(r, L.n_local);
+            L.n_tiles = 0;
+            if (wf_cost_order(r) && r->width % 8 == 0 && L.tile.local_rows % 8 == 0 && L.n_local) {
+                L.n_tiles = L.n_local / 64u;
+                HIPCHK(hipMalloc((void**)&L.d_cost, L.n_local));
+                HIPCHK(hipMalloc((void**)&L.d_tile_key, (size_t)L.n_tiles * 4));
+                HIPCHK(hipMalloc((void**)&L.d_tile_order, (size_t)L.n_tiles * 4));
+            }
             if (chunk > 1 && wf_uses_requeue(r)) { // every pixel is appended once per sample of a launch but its first
                 L.rq_capacity = L.n_local * (chunk - 1u);
                 HIPCHK(hipMalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
@@ -396,14 +414,22 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     uint32_t chunk = r->spp;
     for (uint32_t k = 0; k < K; ++k)
         if (r->lanes[k].n_local) chunk = std::min(chunk, wf_chunk(r, r->lanes[k].n_local));
-    for (uint32_t s = 0; s < r->spp; s += chunk) {
-        const uint32_t n_samples = std::min(chunk, r->spp - s);
+    // cost ordering (one-launch schedule, one stream lane): sample 0 in a launch of its own, then all the others, most expensive blocks first
+    const bool lpt = K == 1 && r->lanes[0].n_tiles != 0 && chunk == r->spp && D0 == 0 && D > 0;
+    for (uint32_t s = 0; s < r->spp;) {
+        const uint32_t n_samples = lpt ? (s == 0 ? 1u : r->spp - 1u) : std::min(chunk, r->spp - s);
+        const bool ordered = lpt && s > 0;
         for (uint32_t k = 0; k < K; ++k) {
             auto& L = r->lanes[k];
             if (L.n_local == 0) continue;
             buf[k] = 0;
+            if (ordered) {
+                hipLaunchKernelGGL(k_wf_tile_cost, dim3(L.n_tiles), dim3(64), 0, L.stream, L.d_cost, (uint32_t)r->width, L.n_tiles, L.d_tile_key);
+                hipLaunchKernelGGL(k_wf_order_tiles, dim3(1), dim3(1024), 0, L.stream, L.d_tile_key, L.n_tiles, L.d_tile_order);
+                launches += 2;
+            }
             hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
-                               L.d_counts + (size_t)s * (D + 1), wf_spread(r) ? 1u : 0u);
+                               L.d_counts + (size_t)s * (D + 1), wf_spread(r) ? 1u : 0u, ordered ? L.d_tile_order : (const uint32_t*)nullptr);
             launches++;
         }
         for (uint32_t d = 0; d < D0; ++d) {
@@ -478,7 +504,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
     hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
                        cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
-                       ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots)
+                       ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots, lpt && s == 0 ? L.d_cost : (uint8_t*)nullptr)
                 if (r->d_stats && req) RT_FINISH_LAUNCH(true, true);
                 else if (r->d_stats) RT_FINISH_LAUNCH(true, false);
                 else if (req) RT_FINISH_LAUNCH(false, true);
@@ -491,6 +517,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 launches++;
             }
         }
+        s += n_samples;
     }
     HIPCHK(hipGetLastError());
     for (uint32_t k = 0; k < K; ++k) {
@@ -903,6 +930,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(0, std::atoi(e)); // 0 = by tile size
         if (const char* e = std::getenv("RT_WF_REQUEUE")) r->wf_requeue = e[0] != '0', r->wf_requeue_set = true;
         r->wf_streams_set = std::getenv("RT_WF_STREAMS") != nullptr;
+        if (const char* e = std::getenv("RT_WF_LPT")) r->wf_lpt = e[0] != '0';
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';
