@@ -268,7 +268,8 @@ bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_one_lau
 // Longest chains first (rt_kernels.h, k_wf_order_tiles): in the one-launch schedule, for tiles of more than one pixel generation, sample 0
 // of every pixel is traced in a launch of its own and the launch for the other samples takes the 8x8 blocks in the order of what their
 // first samples cost. RT_WF_LPT=0 switches it off.
-bool wf_cost_order(const rt_renderer* r) { return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 4; }
+// (from 32 spp on: the extra launch and the sort cost ~1 ms at 4K, 40 % of the cube's 3 ms frame at 16 spp and nothing next to 64 samples)
+bool wf_cost_order(const rt_renderer* r) { return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 32; }
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
 // camera ray on; with the dynamic queue bounded by the entry's 8-bit sample field and the queue's size (<= 1 GiB per stream lane)
