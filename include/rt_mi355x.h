@@ -177,8 +177,8 @@ int32_t rt_renderer_local_rows(const rt_renderer* r);
 /* Global row index of local row `local_row` (for de-interleaving a gathered frame). */
 int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row);
 
-/* Per-launch hipEvent timing of the dominant kernel (k_wf_extend; the megakernel is always timed).
- * Off by default for the wavefront renderer (it adds two event records per bounce); also enabled
+/* Per-launch hipEvent timing of the dominant kernel (k_wf_finish — k_wf_extend in the per-bounce schedule —; the megakernel is
+ * always timed). Off by default for the wavefront renderer (it adds two event records per launch); also enabled
  * by the environment variable RT_PROFILE_KERNELS=1 at renderer creation. No reference counterpart
  * (the reference's print_elapsed helper is commented out: src/render_wavefront.cpp:129-137). */
 int rt_renderer_set_profiling(rt_renderer* r, int enable);
