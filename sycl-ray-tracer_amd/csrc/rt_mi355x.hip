@@ -387,25 +387,27 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     const uint32_t D = r->max_depth;
     if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
     // fork: every lane's stream waits for what was enqueued on `st` so far, then runs its own chain
-    HIPCHK(hipEventRecord(r->ev_fork, st));
+    if (r->lanes.size() > 1) HIPCHK(hipEventRecord(r->ev_fork, st));
     size_t ne_total = 0;
     const uint32_t K = (uint32_t)r->lanes.size();
+    // one stream lane (the default schedule): its launches go straight onto `st` — no fork / join events, no second stream to wake up
+    auto lane_stream = [&](rt_renderer::WfLane& L) { return K == 1 ? st : L.stream; };
     constexpr uint32_t ext_wpb = RT_EXTEND_BLOCK / 64;
     std::vector<uint32_t> grid(K), ext_grid(K), buf(K, 0u);
     std::vector<size_t> ne(K, 0);
     for (uint32_t k = 0; k < K; ++k) {
         auto& L = r->lanes[k];
         L.n_hot = 0;
-        HIPCHK(hipStreamWaitEvent(L.stream, r->ev_fork, 0));
+        if (K > 1) HIPCHK(hipStreamWaitEvent(lane_stream(L), r->ev_fork, 0));
         if (L.n_local == 0) continue;
         grid[k] = (L.n_local + 255u) / 256u;
         // persistent EXTEND waves: fill every SIMD at the kernel's occupancy, never more than there are chunks
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
                                                                             (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
-        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, L.stream));
-        HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, L.stream));
-        hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
+        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L)));
+        HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L)));
+        hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, lane_stream(L), r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
         launches++;
     }
     // the lanes' chains are enqueued round-robin, bounce by bounce, so their kernels interleave on the device
@@ -425,11 +427,11 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             if (L.n_local == 0) continue;
             buf[k] = 0;
             if (ordered) {
-                hipLaunchKernelGGL(k_wf_tile_cost, dim3(L.n_tiles), dim3(64), 0, L.stream, L.d_cost, (uint32_t)r->width, L.n_tiles, L.d_tile_key);
-                hipLaunchKernelGGL(k_wf_order_tiles, dim3(1), dim3(1024), 0, L.stream, L.d_tile_key, L.n_tiles, L.d_tile_order);
+                hipLaunchKernelGGL(k_wf_tile_cost, dim3(L.n_tiles), dim3(64), 0, lane_stream(L), L.d_cost, (uint32_t)r->width, L.n_tiles, L.d_tile_key);
+                hipLaunchKernelGGL(k_wf_order_tiles, dim3(1), dim3(1024), 0, lane_stream(L), L.d_tile_key, L.n_tiles, L.d_tile_order);
                 launches += 2;
             }
-            hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, L.stream, r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
+            hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, lane_stream(L), r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
                                L.d_counts + (size_t)s * (D + 1), wf_spread(r) ? 1u : 0u, ordered ? L.d_tile_order : (const uint32_t*)nullptr);
             launches++;
         }
@@ -437,7 +439,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             for (uint32_t k = 0; k < K; ++k) {
                 auto& L = r->lanes[k];
                 if (L.n_local == 0) continue;
-                hipStream_t ls = L.stream;
+                hipStream_t ls = lane_stream(L);
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
                 hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -476,7 +478,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             for (uint32_t k = 0; k < K; ++k) {
                 auto& L = r->lanes[k];
                 if (L.n_local == 0) continue;
-                hipStream_t ls = L.stream;
+                hipStream_t ls = lane_stream(L);
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
                 // persistent grid: wf_finish_occ waves per SIMD for THIS launch. The lanes' launches overlap on the device, so each asks for
@@ -524,15 +526,17 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     for (uint32_t k = 0; k < K; ++k) {
         auto& L = r->lanes[k];
         if (L.n_local) {
-            hipLaunchKernelGGL(k_wf_resolve, dim3(grid[k]), dim3(256), 0, L.stream, L.n_local, r->spp, (uint32_t)r->width,
+            hipLaunchKernelGGL(k_wf_resolve, dim3(grid[k]), dim3(256), 0, lane_stream(L), L.n_local, r->spp, (uint32_t)r->width,
                                r->tile.strip_rows, K, k, L.d_accum, d_f32, d_u8);
             launches++;
         }
         L.n_hot = ne[k];
         ne_total += ne[k];
         // join: `st` continues only after this lane's chain is complete
-        HIPCHK(hipEventRecord(L.ev_done, L.stream));
-        HIPCHK(hipStreamWaitEvent(st, L.ev_done, 0));
+        if (K > 1) {
+            HIPCHK(hipEventRecord(L.ev_done, lane_stream(L)));
+            HIPCHK(hipStreamWaitEvent(st, L.ev_done, 0));
+        }
     }
     HIPCHK(hipGetLastError());
     *n_hot_events = ne_total;
