@@ -269,7 +269,11 @@ bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_one_lau
 // of every pixel is traced in a launch of its own and the launch for the other samples takes the 8x8 blocks in the order of what their
 // first samples cost. RT_WF_LPT=0 switches it off.
 // (from 32 spp on: the extra launch and the sort cost ~1 ms at 4K, 40 % of the cube's 3 ms frame at 16 spp and nothing next to 64 samples)
-bool wf_cost_order(const rt_renderer* r) { return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 32; }
+// ... and up to four pixel generations: with more, the last generation is a small part of the frame and the order changes nothing
+// (atrium 1080p, 5.3 generations: +0.3 ms for the extra launch)
+bool wf_cost_order(const rt_renderer* r) {
+    return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+}
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
 // camera ray on; with the dynamic queue bounded by the entry's 8-bit sample field and the queue's size (<= 1 GiB per stream lane)
