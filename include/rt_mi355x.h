@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -143,9 +143,12 @@ int rt_scene_check_bvh(const rt_scene* scene);
  * org/dir: 3*n floats (host). Outputs (host, n each): t (+inf on miss), u, v and
  * tri = global triangle index in rt_scene_desc order (0xFFFFFFFF on miss).
  * Range of the contract: the result equals the brute-force closest hit over all triangles (same fp32 Moller-Trumbore) for ray
- * origins within 100 scene diameters of the scene's bounds — every ray the renderers generate. Farther out the fp32 error of
- * the ray itself (~1e-7 x |origin|) exceeds the padding of the BVH boxes (2e-5 x scene scale) and a hit that only exists by
- * that error may be culled. */
+ * origins at most 100 scene scales outside the scene's bounds on any axis (scene scale = max(largest extent of the bounds, largest
+ * |coordinate| of the bounds): what the padding of the BVH boxes, 2e-5 x scale, is derived from) — every ray the renderers
+ * generate from a camera inside that range. Farther out the fp32 error of the ray itself (~1e-7 x |origin|) exceeds the padding and
+ * a hit that only exists by that error could be culled, so the range is ENFORCED: rt_intersect_batch returns RT_ERR_INVALID (naming
+ * the first offending ray) if any origin lies outside it or is not finite, and rt_render_frame* refuse such a camera centre.
+ * The reference's rtcIntersect1 (src/trace_ray.hpp:18-27) states no range; this is a documented narrowing, not a silent one. */
 int rt_intersect_batch(rt_scene* scene, uint32_t n, const float* org, const float* dir, float* t,
                        float* u, float* v, uint32_t* tri);
 
@@ -190,6 +193,62 @@ int rt_renderer_set_profiling(rt_renderer* r, int enable);
  * attenuation / p; otherwise it ends with no contribution. Same rule in both renderers and in the oracle. */
 int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
 
+/* ---- Schedule of the wavefront renderer --------------------------------------------------------------------------------
+ * The reference's WavefrontRenderer::render_frame (src/render_wavefront.cpp:396-431) has ONE schedule: per sample, one
+ * generate_camera_rays launch and one shoot_rays launch per bounce, survivors compacted between bounces (:282-311). This
+ * library renders the same frame (bit for bit) under several schedules; which one runs is chosen here — never silently — and
+ * reported back in rt_stats, per kernel family, so that a test can assert that the kernels it means to test were launched.
+ *   finish_depth        bounces rendered launch by launch: k_wf_extend + k_wf_shade with __ballot / mbcnt compaction of the
+ *                       survivors into the next queue, the reference's shape. The rest of every path is followed by
+ *                       k_wf_finish in one launch. 0 = everything in k_wf_finish (default); RT_SCHED_ALL_BOUNCES (or any
+ *                       value >= max_depth) = the reference's per-bounce schedule.
+ *   samples_per_launch  samples of a pixel one k_wf_finish launch renders. 0 = all of them: ONE launch per frame (default).
+ *   stream_lanes        interleaved sub-tiles rendered on HIP streams of their own. 0 = automatic (1 for the one-launch
+ *                       schedule, 2 otherwise).
+ *   requeue             with samples_per_launch > 1: 1 = a pixel between two samples goes through a device-wide dynamic queue
+ *                       (breadth first), 0 = it stays in its lane (depth first), -1 = automatic.
+ *   reorder, matsort    SURVEY 8(f) row f-3, per-bounce schedule only: k_wf_shade bins a block's survivors by direction octant
+ *                       and 4x4x4 origin cell / partitions a block's rays by material kind before shading.
+ *   cost_order          one-launch schedule: sample 0 in a launch of its own, the other samples with the most expensive 8x8
+ *                       blocks first. -1 = automatic (>= 32 spp, 1..4 pixel generations), 0 = off, 1 = whenever the tile
+ *                       consists of whole 8x8 blocks (a tile that does not falls back to queue order).
+ *   hip_graph           1 = the frame's launches are captured once and replayed as a hipGraph.
+ * The environment variables RT_WF_FINISH_DEPTH / _SAMPLES_PER_LAUNCH / _STREAMS / _REQUEUE / _REORDER / _MATSORT / _LPT /
+ * _GRAPH still work: rt_renderer_create turns them into the initial rt_schedule (a shim for scripts; tests use the API). */
+#define RT_SCHED_ALL_BOUNCES 0xFFFFFFFFu
+typedef struct rt_schedule {
+    uint32_t finish_depth;
+    uint32_t samples_per_launch;
+    uint32_t stream_lanes;
+    int32_t requeue;
+    uint32_t reorder;
+    uint32_t matsort;
+    int32_t cost_order;
+    uint32_t hip_graph;
+} rt_schedule;
+/* Megakernel renderers accept the call and ignore every field. No frame may be in flight; the tile's queues are re-allocated. */
+int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s);
+int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out);
+
+/* Kernel families, for rt_stats::launches_by_kernel. A k_wf_shade launch counts in RT_K_WF_SHADE and, when the flags are on,
+ * also in RT_K_WF_SHADE_REORDER / RT_K_WF_SHADE_MATSORT; a k_wf_finish launch with the dynamic queue counts in RT_K_WF_FINISH
+ * and RT_K_WF_FINISH_REQUEUE. */
+enum {
+    RT_K_MEGAKERNEL = 0,
+    RT_K_WF_INIT = 1,
+    RT_K_WF_GENERATE = 2,
+    RT_K_WF_EXTEND = 3,
+    RT_K_WF_SHADE = 4,
+    RT_K_WF_SHADE_REORDER = 5,
+    RT_K_WF_SHADE_MATSORT = 6,
+    RT_K_WF_FINISH = 7,
+    RT_K_WF_FINISH_REQUEUE = 8,
+    RT_K_WF_TILE_ORDER = 9, /* k_wf_tile_cost + k_wf_order_tiles (cost ordering) */
+    RT_K_WF_RESOLVE = 10,
+    RT_K_FILL_BLACK = 11,
+    RT_K_COUNT = 16
+};
+
 typedef struct rt_stats {
     uint64_t rays;       /* trace_ray calls (src/render_megakernel.cpp:32, render_wavefront.cpp:407) */
     double seconds;      /* host wall clock, first launch -> last kernel complete                  */
@@ -197,6 +256,12 @@ typedef struct rt_stats {
     double hot_kernel_ms;/* summed duration of the dominant kernel's launches (hipEvents), or 0    */
     uint32_t hot_kernel_launches;
     uint32_t launches;   /* kernel launches issued for the frame                                   */
+    /* what actually ran (ABI 5): launches of the frame per kernel family, and the schedule as it was resolved for this tile */
+    uint32_t launches_by_kernel[RT_K_COUNT];
+    uint32_t stream_lanes;       /* HIP streams the frame's launch chains ran on (1 for the megakernel)            */
+    uint32_t samples_per_launch; /* samples of a pixel per k_wf_finish launch as resolved (spp = one launch per frame) */
+    uint32_t finish_depth;       /* bounces rendered as EXTEND + SHADE launch pairs, min(schedule, max_depth)      */
+    uint32_t cost_ordered;       /* 1 = the cost-ordered second launch ran                                          */
 } rt_stats;
 
 /* == IRenderer::render_frame(camera, scene) (src/render_megakernel.cpp:75-187,
@@ -247,6 +312,14 @@ void* rt_renderer_tile_u8(rt_renderer* r);
  * through want_device_*). The device-resident frame stays valid until the next gather: rt_comm_frame_f32 / _u8. */
 int rt_frame_gather(rt_comm* c, rt_renderer* const* renderers, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32,
                     int want_device_u8);
+/* The same in two calls. _begin only ENQUEUES the collective and the de-interleave (event waits between the renderers' streams
+ * and the root's; no host wait): a renderer's next frame may be begun right after it and overlaps with the gather. rt_comm_wait
+ * blocks until the gathered frame is complete on the root device and copies it to the host where a pointer is given.
+ * If a collective fails half-way the communicator is marked unusable (every later call returns RT_ERR_HIP): destroy it and
+ * create a new one. */
+int rt_frame_gather_begin(rt_comm* c, rt_renderer* const* renderers, int want_f32, int want_u8);
+int rt_comm_wait(rt_comm* c, float* rgba_f32, uint8_t* rgba_u8);
+int rt_comm_size(const rt_comm* c); /* ranks of the communicator (with RCCL: what ncclCommInitAll was given) */
 const void* rt_comm_frame_f32(const rt_comm* c);
 const void* rt_comm_frame_u8(const rt_comm* c);
 

@@ -130,7 +130,7 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
     RT_DEV uint32_t threshold() const { return (w >> 28) + 1u; }
     RT_DEV void stepped() { // one iteration of the traversal loop (RT_MEGA_UNROLL steps)
 #if RT_MEGA_REFILL_ADAPTIVE
-        w += 1u << 17;
+        if (((w >> 17) & 0x7FFu) != 0x7FFu) w += 1u << 17; // saturates: a carry would drift into the threshold field (deep trees, slow tail waves)
 #endif
     }
     // after every shading round, in wave-uniform control flow; `finished`: this lane has just finished its pixel (or, where queue slots
@@ -139,7 +139,8 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
 #if RT_MEGA_REFILL_ADAPTIVE
         w += ((uint32_t)__popcll(__ballot(finished)) << 5) + 1u;
         if ((w & 31u) == 0u) { // 32 rounds
-            const uint32_t ended = (w >> 5) & 0xFFFu, steps = ((w >> 17) & 0x7FFu) * RT_MEGA_UNROLL;
+            // (the round counter's carry out of bits 0-4 has just added one to the `ended` field: taken off again)
+            const uint32_t ended = ((w >> 5) & 0xFFFu) - 1u, steps = ((w >> 17) & 0x7FFu) * RT_MEGA_UNROLL;
             const uint32_t num = 320u * ended, den = 160u + steps;
             const uint32_t t = num < 4u * den ? 1u : num < 9u * den ? 2u : num < 16u * den ? 3u : num < 25u * den ? 4u : num < 36u * den ? 5u
                                : num < 64u * den ? 6u : num < 100u * den ? 8u : num < 144u * den ? 10u : num < 256u * den ? 12u : 16u;

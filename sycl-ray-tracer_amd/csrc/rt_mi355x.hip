@@ -122,6 +122,14 @@ struct rt_scene {
     uint64_t device_bytes = 0;
 };
 
+// kernel launches of one frame, in all and per kernel family (rt_stats::launches_by_kernel)
+struct LaunchCount {
+    uint32_t total = 0;
+    uint32_t by[RT_K_COUNT] = {};
+    void add(int kernel, uint32_t n = 1) { total += n, by[kernel] += n; }
+    void also(int kernel, uint32_t n = 1) { by[kernel] += n; } // a second family of a launch already counted
+};
+
 struct rt_renderer {
     int kind = 0;
     rt_scene* scene = nullptr;
@@ -179,24 +187,19 @@ struct rt_renderer {
     // two branches no longer overlap), so plain launches stay the default.
     CameraDev* d_cam = nullptr;
     CameraDev* h_cam = nullptr;
-    bool use_graph = false;
-    // f-3: re-ordering of the ray queue between bounces, both OFF by default (measured: profiles/r02_reorder.json)
-    //   wf_reorder : SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the origin) before it writes them
-    //   wf_matsort : SHADE partitions a block's rays by material kind before shading them, so that a wave shades one kind
-    bool wf_reorder = false, wf_matsort = false;
-    // bounces rendered launch by launch (EXTEND + SHADE) before k_wf_finish follows the surviving rays to the end of their paths in
-    // one launch per sample; >= max_depth = the reference's schedule (a launch pair per bounce). RT_WF_FINISH_DEPTH overrides.
-    uint32_t wf_finish_depth = RT_WF_FINISH_DEPTH_DEFAULT;
-    uint32_t wf_samples_per_launch = RT_WF_SAMPLES_PER_LAUNCH_DEFAULT; // RT_WF_SAMPLES_PER_LAUNCH
-    bool wf_streams_set = false, wf_requeue_set = false; // RT_WF_STREAMS / RT_WF_REQUEUE given: no automatic choice of the regime
-    bool wf_lpt = true;     // cost-ordered second launch of the one-launch schedule (RT_WF_LPT=0: off)
-    bool wf_requeue = true; // with several samples per launch: breadth first through a device-wide dynamic queue (RT_WF_REQUEUE=0: the lane keeps its pixel)
-    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC)
+    // The wavefront renderer's schedule (include/rt_mi355x.h: rt_schedule), set through rt_renderer_set_schedule; the RT_WF_*
+    // environment variables only fill the initial value at rt_renderer_create. What ran is reported in rt_stats.
+    //   finish_depth: bounces rendered launch by launch (EXTEND + SHADE) before k_wf_finish follows the surviving rays to the end of
+    //   their paths; >= max_depth = the reference's schedule (a launch pair per bounce).
+    //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
+    //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
+    rt_schedule sched{RT_WF_FINISH_DEPTH_DEFAULT, RT_WF_SAMPLES_PER_LAUNCH_DEFAULT, 0u, -1, 0u, 0u, -1, 0u};
+    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC, tuning)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
     uint8_t* graph_u8 = nullptr;
     hipStream_t graph_stream = nullptr;
-    uint32_t graph_launches = 0;
+    LaunchCount graph_launches{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // the frame between rt_render_frame_begin and rt_render_frame_end
     bool frame_pending = false;
@@ -248,6 +251,25 @@ void drain_streams(rt_renderer* r, hipStream_t extra) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
 }
 
+// Range of the closest-hit contract (include/rt_mi355x.h, rt_intersect_batch): a ray origin may lie at most kContractRange scene
+// scales outside the scene's bounds on any axis, the scene scale being what the padding of the BVH boxes is derived from
+// (scene_build.cpp: max(largest extent, largest |coordinate|)). Farther out the fp32 rounding of the ray itself exceeds the padding
+// and the box test could cull a hit the triangle test would report; the entry points refuse such origins instead of answering
+// silently wrong. NaN origins are refused too.
+constexpr float kContractRange = 100.0f;
+bool origin_in_contract_range(const HostScene& hs, const float o[3]) {
+    if (hs.wverts.empty()) return std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]); // nothing to cull
+    float scale = 0.0f;
+    for (int a = 0; a < 3; ++a)
+        scale = std::max(scale, std::max(hs.bounds_hi[a] - hs.bounds_lo[a], std::max(std::fabs(hs.bounds_lo[a]), std::fabs(hs.bounds_hi[a]))));
+    const float limit = kContractRange * scale;
+    for (int a = 0; a < 3; ++a) {
+        const float outside = std::max(std::max(hs.bounds_lo[a] - o[a], o[a] - hs.bounds_hi[a]), 0.0f);
+        if (!(outside <= limit)) return false;
+    }
+    return true;
+}
+
 int32_t rows_of_tile(const TileDev& t, int32_t height) {
     int32_t rows = 0;
     for (int32_t y = 0; y < height; ++y)
@@ -255,32 +277,35 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
     return rows;
 }
 
-// The wavefront renderer's default schedule: ONE k_wf_generate + ONE k_wf_finish launch per frame and tile, on one stream lane, every
-// pixel kept in its lane for all its samples (rt_kernels.h). It applies unless the environment asks for one of the other schedules
-// (RT_WF_SAMPLES_PER_LAUNCH, RT_WF_REQUEUE, RT_WF_STREAMS, RT_WF_FINISH_DEPTH), which stay in the tree with their tests.
-bool wf_one_launch(const rt_renderer* r) {
-    return r->wf_samples_per_launch == 0 && !r->wf_streams_set && !r->wf_requeue_set && r->wf_finish_depth == 0 && r->max_depth > 0;
-}
+// The wavefront renderer's default schedule: ONE k_wf_generate + ONE k_wf_finish launch per frame, tile and stream lane, every
+// pixel kept in its lane for all its samples (rt_kernels.h): rt_schedule{finish_depth 0, samples_per_launch 0}.
+bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch == 0 && r->sched.finish_depth == 0 && r->max_depth > 0; }
+// stream lanes (interleaved sub-tiles on HIP streams of their own): 1 for the one-launch schedule, 2 where launches have tails to overlap
+uint32_t wf_stream_lanes(const rt_renderer* r) { return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : 2u); }
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
-bool wf_spread(const rt_renderer* r) { return wf_one_launch(r) && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u; }
-bool wf_uses_requeue(const rt_renderer* r) { return r->wf_requeue && !wf_one_launch(r); }
+bool wf_spread(const rt_renderer* r) {
+    return wf_one_launch(r) && wf_stream_lanes(r) == 1 && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+}
+bool wf_uses_requeue(const rt_renderer* r) { return r->sched.requeue != 0 && !wf_one_launch(r); }
 // Longest chains first (rt_kernels.h, k_wf_order_tiles): in the one-launch schedule, for tiles of more than one pixel generation, sample 0
 // of every pixel is traced in a launch of its own and the launch for the other samples takes the 8x8 blocks in the order of what their
-// first samples cost. RT_WF_LPT=0 switches it off.
-// (from 32 spp on: the extra launch and the sort cost ~1 ms at 4K, 40 % of the cube's 3 ms frame at 16 spp and nothing next to 64 samples)
+// first samples cost. rt_schedule::cost_order: -1 automatic (below), 0 off, 1 whenever the tile consists of whole 8x8 blocks.
+// (automatic: from 32 spp on: the extra launch and the sort cost ~1 ms at 4K, 40 % of the cube's 3 ms frame at 16 spp and nothing next to 64 samples)
 // ... and up to four pixel generations: with more, the last generation is a small part of the frame and the order changes nothing
 // (atrium 1080p, 5.3 generations: +0.3 ms for the extra launch)
 bool wf_cost_order(const rt_renderer* r) {
-    return r->wf_lpt && wf_one_launch(r) && !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+    if (r->sched.cost_order == 0 || !wf_one_launch(r) || wf_stream_lanes(r) != 1) return false;
+    if (r->sched.cost_order > 0) return true;
+    return !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * RT_MEGA_WAVES * 64u;
 }
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
 // camera ray on; with the dynamic queue bounded by the entry's 8-bit sample field and the queue's size (<= 1 GiB per stream lane)
 uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
-    if (r->wf_finish_depth != 0 || r->max_depth == 0 || n_local == 0) return 1u;
+    if (r->sched.finish_depth != 0 || r->max_depth == 0 || n_local == 0) return 1u;
     if (wf_one_launch(r)) return r->spp;
-    uint64_t c = std::min<uint32_t>(std::max(1u, r->wf_samples_per_launch), r->spp);
+    uint64_t c = std::min<uint32_t>(std::max(1u, r->sched.samples_per_launch), r->spp);
     if (wf_uses_requeue(r)) {
         c = std::min<uint64_t>(c, 256u);
         c = std::min<uint64_t>(c, std::max<uint64_t>(1, ((1ull << 30) / 8) / n_local + 1));
@@ -320,8 +345,8 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
         }
     } else {
-        uint32_t K = wf_one_launch(r) ? 1u : 2u;
-        if (const char* e = std::getenv("RT_WF_STREAMS")) K = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+        const uint32_t K = wf_stream_lanes(r);
+        const bool per_bounce = r->sched.finish_depth > 0 && r->max_depth > 0; // EXTEND + SHADE launch pairs: the second queue and the hit records
         r->lanes.resize(K);
         for (uint32_t k = 0; k < K; ++k) {
             auto& L = r->lanes[k];
@@ -330,7 +355,8 @@ int alloc_tile_buffers(rt_renderer* r) {
             L.tile.local_rows = rows_of_tile(L.tile, r->height);
             L.n_local = (uint32_t)L.tile.local_rows * (uint32_t)r->width;
             const size_t m = std::max<size_t>(L.n_local, 1);
-            for (auto& q : L.q) {
+            for (int qi = 0; qi < (per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
+                auto& q = L.q[qi];
                 HIPCHK(hipMalloc((void**)&q.org_id, m * 16));
                 HIPCHK(hipMalloc((void**)&q.a, m * 8));
                 HIPCHK(hipMalloc((void**)&q.b, m * 8));
@@ -338,7 +364,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             }
             HIPCHK(hipMalloc((void**)&L.d_rng, m * 4));
             HIPCHK(hipMalloc((void**)&L.d_accum, m * 16));
-            HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
+            if (per_bounce) HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
             const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
             // spp * (max_depth + 1) queue lengths, spp * max_depth chunk cursors, spp "extra ray" counters of k_wf_finish
             HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
@@ -384,9 +410,9 @@ hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i) {
 
 // The wavefront frame: every launch of the lanes' chains, forked from and joined back into `st`. Issued directly
 // or recorded by a stream capture (enqueue_frame).
-int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t st, uint32_t* launches_out, size_t* n_hot_events) {
+int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t st, LaunchCount* launches_out, size_t* n_hot_events) {
     const SceneDev& S = r->scene->dev;
-    uint32_t launches = 0;
+    LaunchCount launches;
     HIPCHK(hipMemcpyAsync(r->d_cam, r->h_cam, sizeof(CameraDev), hipMemcpyHostToDevice, st));
     const uint32_t D = r->max_depth;
     if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
@@ -412,10 +438,10 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L)));
         HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L)));
         hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, lane_stream(L), r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
-        launches++;
+        launches.add(RT_K_WF_INIT);
     }
     // the lanes' chains are enqueued round-robin, bounce by bounce, so their kernels interleave on the device
-    const uint32_t D0 = std::min(D, r->wf_finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
+    const uint32_t D0 = std::min(D, r->sched.finish_depth); // bounces done launch by launch; the rest of every path in k_wf_finish
     // samples one k_wf_finish launch renders per pixel: when it takes over from the camera ray on (D0 == 0) a lane whose path has ended
     // generates the pixel's NEXT sample itself and goes on, for `chunk` samples, before it hands the RNG word back to memory
     uint32_t chunk = r->spp;
@@ -433,11 +459,11 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             if (ordered) {
                 hipLaunchKernelGGL(k_wf_tile_cost, dim3(L.n_tiles), dim3(64), 0, lane_stream(L), L.d_cost, (uint32_t)r->width, L.n_tiles, L.d_tile_key);
                 hipLaunchKernelGGL(k_wf_order_tiles, dim3(1), dim3(1024), 0, lane_stream(L), L.d_tile_key, L.n_tiles, L.d_tile_order);
-                launches += 2;
+                launches.add(RT_K_WF_TILE_ORDER, 2);
             }
             hipLaunchKernelGGL(k_wf_generate, dim3(grid[k]), dim3(256), 0, lane_stream(L), r->d_cam, L.tile, L.n_local, L.d_rng, L.q[0],
                                L.d_counts + (size_t)s * (D + 1), wf_spread(r) ? 1u : 0u, ordered ? L.d_tile_order : (const uint32_t*)nullptr);
-            launches++;
+            launches.add(RT_K_WF_GENERATE);
         }
         for (uint32_t d = 0; d < D0; ++d) {
             for (uint32_t k = 0; k < K; ++k) {
@@ -467,13 +493,15 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #define RT_SHADE_LAUNCH(RE, MS)                                                                                                         \
     hipLaunchKernelGGL((k_wf_shade<RE, MS>), dim3(grid[k]), dim3(256), 0, ls, S, L.q[buf[k]], L.q[buf[k] ^ 1], L.d_hits, L.d_rng, L.d_accum, \
                        counts + d, counts + d + 1, last, rr)
-                    if (r->wf_reorder && r->wf_matsort) RT_SHADE_LAUNCH(true, true);
-                    else if (r->wf_reorder) RT_SHADE_LAUNCH(true, false);
-                    else if (r->wf_matsort) RT_SHADE_LAUNCH(false, true);
+                    if (r->sched.reorder && r->sched.matsort) RT_SHADE_LAUNCH(true, true);
+                    else if (r->sched.reorder) RT_SHADE_LAUNCH(true, false);
+                    else if (r->sched.matsort) RT_SHADE_LAUNCH(false, true);
                     else RT_SHADE_LAUNCH(false, false);
 #undef RT_SHADE_LAUNCH
                 }
-                launches += 2;
+                launches.add(RT_K_WF_EXTEND), launches.add(RT_K_WF_SHADE);
+                if (r->sched.reorder) launches.also(RT_K_WF_SHADE_REORDER);
+                if (r->sched.matsort) launches.also(RT_K_WF_SHADE_MATSORT);
                 buf[k] ^= 1;
             }
         }
@@ -521,7 +549,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     HIPCHK(hipEventRecord(e1, ls));
                     ne[k] += 2;
                 }
-                launches++;
+                launches.add(RT_K_WF_FINISH);
+                if (req) launches.also(RT_K_WF_FINISH_REQUEUE);
             }
         }
         s += n_samples;
@@ -532,7 +561,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         if (L.n_local) {
             hipLaunchKernelGGL(k_wf_resolve, dim3(grid[k]), dim3(256), 0, lane_stream(L), L.n_local, r->spp, (uint32_t)r->width,
                                r->tile.strip_rows, K, k, L.d_accum, d_f32, d_u8);
-            launches++;
+            launches.add(RT_K_WF_RESOLVE);
         }
         L.n_hot = ne[k];
         ne_total += ne[k];
@@ -553,7 +582,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                   size_t* n_hot_events) {
     const CameraDev c = to_dev(*cam);
     const SceneDev& S = r->scene->dev;
-    uint32_t launches = 0;
+    LaunchCount launches;
     *n_hot_events = 0;
     if (r->n_local == 0) {
         if (stats) stats->launches = 0;
@@ -599,11 +628,12 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
         *n_hot_events = 2;
-        launches = 1;
+        launches.add(r->max_depth == 0 ? RT_K_FILL_BLACK : RT_K_MEGAKERNEL);
+        if (stats) stats->stream_lanes = 1, stats->samples_per_launch = r->spp;
     } else {
         *r->h_cam = c;
         size_t ne_total = 0;
-        if (!(r->use_graph && !r->profile_kernels && !r->d_stats)) {
+        if (!(r->sched.hip_graph && !r->profile_kernels && !r->d_stats)) {
             int rc = enqueue_wavefront(r, d_f32, d_u8, st, &launches, &ne_total);
             if (rc != RT_OK) return rc;
         } else {
@@ -629,8 +659,20 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
             launches = r->graph_launches;
         }
         *n_hot_events = ne_total;
+        if (stats) { // the schedule as it was resolved for this tile
+            stats->stream_lanes = (uint32_t)r->lanes.size();
+            stats->finish_depth = std::min(r->max_depth, r->sched.finish_depth);
+            uint32_t chunk = r->spp;
+            for (auto& L : r->lanes)
+                if (L.n_local) chunk = std::min(chunk, wf_chunk(r, L.n_local));
+            stats->samples_per_launch = chunk;
+            stats->cost_ordered = launches.by[RT_K_WF_TILE_ORDER] ? 1u : 0u;
+        }
     }
-    if (stats) stats->launches = launches;
+    if (stats) {
+        stats->launches = launches.total;
+        std::memcpy(stats->launches_by_kernel, launches.by, sizeof(launches.by));
+    }
     return RT_OK;
 }
 
@@ -640,6 +682,8 @@ int frame_begin(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
     if (!r || !cam) return fail(RT_ERR_INVALID, "null renderer or camera");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "the renderer's previous frame has not been collected (rt_render_frame_end)");
     if (cam->width != r->width || cam->height != r->height) return fail(RT_ERR_INVALID, "camera size differs from the renderer's image size");
+    if (!origin_in_contract_range(r->scene->hs, cam->center))
+        return fail(RT_ERR_INVALID, "the camera lies more than 100 scene scales outside the scene's bounds: outside the range of the closest-hit contract (rt_intersect_batch)");
     HIPCHK(hipSetDevice(r->scene->device));
     r->pending_stats = rt_stats{};
     r->pending_hot = 0;
@@ -875,6 +919,9 @@ int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* d
     if (!s || (n && (!org || !dir || !t || !u || !v || !tri))) return fail(RT_ERR_INVALID, "null argument");
     if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
     if (n == 0) return RT_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!origin_in_contract_range(s->hs, org + 3 * (size_t)i))
+            return fail(RT_ERR_INVALID, "ray " + std::to_string(i) + ": origin more than 100 scene scales outside the scene's bounds (outside the range of the closest-hit contract)");
     HIPCHK(hipSetDevice(s->device));
     DevBuf b_org, b_dir, b_out;
     HIPCHK(b_org.alloc((size_t)n * 12));
@@ -934,15 +981,19 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     if (kind == RT_RENDERER_WAVEFRONT) {
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
-        if (const char* e = std::getenv("RT_WF_GRAPH")) r->use_graph = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) r->wf_finish_depth = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) r->wf_samples_per_launch = (uint32_t)std::max(0, std::atoi(e)); // 0 = by tile size
-        if (const char* e = std::getenv("RT_WF_REQUEUE")) r->wf_requeue = e[0] != '0', r->wf_requeue_set = true;
-        r->wf_streams_set = std::getenv("RT_WF_STREAMS") != nullptr;
-        if (const char* e = std::getenv("RT_WF_LPT")) r->wf_lpt = e[0] != '0';
+        // Environment shim for scripts (the API is rt_renderer_set_schedule; tests use that): the variables fill the initial schedule.
+        // RT_WF_STREAMS / RT_WF_REQUEUE alone have always meant "not the one-launch schedule": they imply a launch per sample.
+        rt_schedule& sc = r->sched;
+        if (const char* e = std::getenv("RT_WF_GRAPH")) sc.hip_graph = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) sc.finish_depth = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) sc.samples_per_launch = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("RT_WF_REQUEUE")) sc.requeue = e[0] != '0' ? 1 : 0;
+        if (const char* e = std::getenv("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+        if ((std::getenv("RT_WF_REQUEUE") || std::getenv("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
+        if (const char* e = std::getenv("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
-        if (const char* e = std::getenv("RT_WF_REORDER")) r->wf_reorder = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_MATSORT")) r->wf_matsort = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_REORDER")) sc.reorder = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
     }
     rc = no_throw([&] { return alloc_tile_buffers(r); });
     if (rc != RT_OK) return bail(rc);
@@ -997,6 +1048,25 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce) {
     return RT_OK;
 }
 
+int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out) {
+    if (!r || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = r->sched;
+    return RT_OK;
+}
+
+int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
+    if (!r || !s) return fail(RT_ERR_INVALID, "null argument");
+    if (s->stream_lanes > 8) return fail(RT_ERR_INVALID, "at most 8 stream lanes");
+    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1)
+        return fail(RT_ERR_INVALID, "schedule field out of range");
+    if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
+    if (r->kind != RT_RENDERER_WAVEFRONT) return RT_OK; // the megakernel is one launch: nothing to schedule
+    HIPCHK(hipSetDevice(r->scene->device));
+    drain_streams(r, r->pending_stream); // the queues are re-allocated (stream lanes, second queue, hit records, dynamic queue)
+    r->sched = *s;
+    return no_throw([&] { return alloc_tile_buffers(r); });
+}
+
 int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8, rt_stats* stats) {
     if (!r) return fail(RT_ERR_INVALID, "null renderer");
     int rc = no_throw([&] { return render_impl(r, cam, rgba_f32 ? r->d_f32 : nullptr, rgba_u8 ? r->d_u8 : nullptr, r->stream, stats); });
@@ -1035,6 +1105,7 @@ struct RcclApi {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGather) Gather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err; // why the library is unusable: dlerror() read ONCE, right after the failing call (a second dlerror() returns NULL)
     bool ok() const { return lib && CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString; }
 };
 
@@ -1044,14 +1115,25 @@ RcclApi& rccl() { // loaded once, on the first rt_comm_create that needs it
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            const char* e = dlerror();
+            a.err = e ? e : "dlopen failed";
         }
         if (a.lib) {
-            a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.lib, "ncclCommInitAll");
-            a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
-            a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
-            a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
-            a.Gather = (decltype(a.Gather))dlsym(a.lib, "ncclGather");
-            a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+            a.err.clear();
+            auto sym = [&a](const char* name) {
+                void* f = dlsym(a.lib, name);
+                if (!f && a.err.empty()) {
+                    const char* e = dlerror();
+                    a.err = e ? e : (std::string("symbol missing: ") + name);
+                }
+                return f;
+            };
+            a.CommInitAll = (decltype(a.CommInitAll))sym("ncclCommInitAll");
+            a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+            a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+            a.Gather = (decltype(a.Gather))sym("ncclGather");
+            a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
         }
         return a;
     }();
@@ -1092,6 +1174,13 @@ struct rt_comm {
     float4* d_full_f32 = nullptr;
     uint32_t* d_full_u8 = nullptr;
     hipStream_t root_stream = nullptr;
+    // ordering without host waits: ev_tile[i] (on device i) marks "tile i's strips have left / arrived" on renderer i's stream,
+    // ev_frame (root) marks "the de-interleave has read the gather buffer": the next gather's receive waits for it
+    std::vector<hipEvent_t> ev_tile;
+    hipEvent_t ev_frame = nullptr;
+    bool frame_recorded = false;
+    bool gathered_f32 = false, gathered_u8 = false; // planes of the last rt_frame_gather_begin
+    bool broken = false; // a collective failed half-way: the communicators are unusable (rt_comm_destroy + rt_comm_create)
 };
 
 namespace {
@@ -1124,10 +1213,16 @@ int rt_comm_create(int n, const int* devices, rt_comm** out) {
             rt_comm_destroy(c);
             return code;
         };
-        if (hipSetDevice(devices[0]) != hipSuccess || hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking) != hipSuccess)
+        if (hipSetDevice(devices[0]) != hipSuccess || hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming) != hipSuccess)
             return bail(fail(RT_ERR_HIP, "cannot create a stream on the root device"));
+        c->ev_tile.assign((size_t)n, nullptr);
+        for (int i = 0; i < n; ++i)
+            if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&c->ev_tile[(size_t)i], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(RT_ERR_HIP, "cannot create an event on device " + std::to_string(devices[i])));
+        (void)hipSetDevice(devices[0]);
         if (distinct) { // one rank per device: RCCL over xGMI
-            if (!rccl().ok()) return bail(fail(RT_ERR_UNSUPPORTED, std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing")));
+            if (!rccl().ok()) return bail(fail(RT_ERR_UNSUPPORTED, "librccl.so could not be loaded: " + (rccl().err.empty() ? std::string("symbols missing") : rccl().err)));
             c->comms.assign((size_t)n, nullptr);
             const ncclResult_t rc = rccl().CommInitAll(c->comms.data(), n, devices);
             if (rc != ncclSuccess) {
@@ -1145,9 +1240,12 @@ void rt_comm_destroy(rt_comm* c) {
     if (!c) return;
     for (size_t i = 0; i < c->comms.size(); ++i)
         if (c->comms[i] && hipSetDevice(c->devices[i]) == hipSuccess) (void)rccl().CommDestroy(c->comms[i]);
+    for (size_t i = 0; i < c->ev_tile.size(); ++i)
+        if (c->ev_tile[i] && hipSetDevice(c->devices[i]) == hipSuccess) (void)hipEventDestroy(c->ev_tile[i]);
     if (!c->devices.empty() && hipSetDevice(c->devices[0]) == hipSuccess) {
         if (c->root_stream) (void)hipStreamSynchronize(c->root_stream);
         comm_free_buffers(c);
+        if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
         if (c->root_stream) (void)hipStreamDestroy(c->root_stream);
     }
     delete c;
@@ -1159,10 +1257,18 @@ const void* rt_comm_frame_u8(const rt_comm* c) { return c ? c->d_full_u8 : nullp
 void* rt_renderer_tile_f32(rt_renderer* r) { return r ? r->d_f32 : nullptr; }
 void* rt_renderer_tile_u8(rt_renderer* r) { return r ? r->d_u8 : nullptr; }
 
-int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32, int want_device_u8) {
+// Enqueues the gather of the renderers' last frames and returns at once: nothing in here waits on the host. Order on the device:
+//   renderer i's stream : [frame i rendered] -> (root only: wait ev_frame = the previous de-interleave has read the gather buffer)
+//                         -> ncclGather send (root: + receive) -> record ev_tile[i]
+//   root stream         : wait ev_tile[0] (RCCL: the receive is complete when the root's part of the collective is; device copies:
+//                         wait every ev_tile[i], then the copies) -> k_deinterleave -> record ev_frame
+// A renderer's next frame is enqueued on its own stream behind its send, so the caller may begin the next frame right after this
+// call and collect this one later with rt_comm_wait: the gather overlaps with the next frame's traversal.
+int rt_frame_gather_begin(rt_comm* c, rt_renderer* const* rs, int want_f32, int want_u8) {
     if (!c || !rs) return fail(RT_ERR_INVALID, "null communicator or renderer list");
+    if (c->broken) return fail(RT_ERR_HIP, "a collective of this communicator failed: destroy it and create a new one");
     const uint32_t n = (uint32_t)c->devices.size();
-    const bool f32 = rgba_f32 || want_device_f32, u8 = rgba_u8 || want_device_u8;
+    const bool f32 = want_f32 != 0, u8 = want_u8 != 0;
     if (!f32 && !u8) return fail(RT_ERR_INVALID, "nothing to gather: ask for the f32 and / or the u8 plane");
     for (uint32_t i = 0; i < n; ++i) {
         const rt_renderer* r = rs[i];
@@ -1182,6 +1288,7 @@ int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t
             HIPCHK(hipStreamSynchronize(c->root_stream));
             comm_free_buffers(c);
             c->width = W, c->height = H, c->rows_max = rows_max;
+            c->frame_recorded = false;
         }
         if (f32 && !c->d_full_f32) {
             HIPCHK(hipMalloc((void**)&c->d_gather_f32, std::max<size_t>(1, tile_px * n) * 16));
@@ -1191,30 +1298,44 @@ int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t
             HIPCHK(hipMalloc((void**)&c->d_gather_u8, std::max<size_t>(1, tile_px * n) * 4));
             HIPCHK(hipMalloc((void**)&c->d_full_u8, std::max<size_t>(1, frame_px) * 4));
         }
+        c->gathered_f32 = f32, c->gathered_u8 = u8;
         if (frame_px == 0) return RT_OK;
         if (c->use_rccl) {
+            // the previous frame's de-interleave must have read the gather buffer before the root receives into it again
+            if (c->frame_recorded) HIPCHK(hipStreamWaitEvent(rs[0]->stream, c->ev_frame, 0));
             // ONE grouped collective per plane: every rank sends rows_max * W pixels from its own stream (ordered behind its
-            // render), the root receives n blocks. Single-process multi-device RCCL calls must be grouped (rccl.h:213).
-            NCCLCHK(rccl().GroupStart());
-            for (uint32_t i = 0; i < n; ++i) {
-                HIPCHK(hipSetDevice(c->devices[i]));
-                if (f32) NCCLCHK(rccl().Gather(rs[i]->d_f32, i == 0 ? (void*)c->d_gather_f32 : nullptr, tile_px * 4, ncclFloat, 0, c->comms[i], rs[i]->stream));
-                if (u8) NCCLCHK(rccl().Gather(rs[i]->d_u8, i == 0 ? (void*)c->d_gather_u8 : nullptr, tile_px * 4, ncclUint8, 0, c->comms[i], rs[i]->stream));
+            // render), the root receives n blocks. Single-process multi-device RCCL calls must be grouped (rccl.h:213). An error
+            // inside the group is remembered and the group is CLOSED all the same: returning between GroupStart and GroupEnd would
+            // leave this thread's group open and every later collective queued instead of issued.
+            ncclResult_t first = rccl().GroupStart();
+            if (first != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGroupStart: ") + rccl().GetErrorString(first));
+            std::string what;
+            for (uint32_t i = 0; i < n && first == ncclSuccess; ++i) {
+                if (hipSetDevice(c->devices[i]) != hipSuccess) {
+                    first = ncclUnhandledCudaError, what = "hipSetDevice";
+                    break;
+                }
+                if (f32) first = rccl().Gather(rs[i]->d_f32, i == 0 ? (void*)c->d_gather_f32 : nullptr, tile_px * 4, ncclFloat, 0, c->comms[i], rs[i]->stream), what = "ncclGather (f32)";
+                if (u8 && first == ncclSuccess) first = rccl().Gather(rs[i]->d_u8, i == 0 ? (void*)c->d_gather_u8 : nullptr, tile_px * 4, ncclUint8, 0, c->comms[i], rs[i]->stream), what = "ncclGather (u8)";
             }
-            NCCLCHK(rccl().GroupEnd());
-            for (uint32_t i = 0; i < n; ++i) { // the root's stream receives; the others only have to have sent
-                HIPCHK(hipSetDevice(c->devices[i]));
-                HIPCHK(hipStreamSynchronize(rs[i]->stream));
+            const ncclResult_t ge = rccl().GroupEnd();
+            (void)hipSetDevice(c->devices[0]);
+            if (first != ncclSuccess || ge != ncclSuccess) {
+                c->broken = true; // part of the collective may be queued on some ranks' streams and never complete
+                return fail(RT_ERR_HIP, (first != ncclSuccess ? what : std::string("ncclGroupEnd")) + ": " + rccl().GetErrorString(first != ncclSuccess ? first : ge) +
+                                            " (the communicator is unusable now: rt_comm_destroy + rt_comm_create)");
             }
-            HIPCHK(hipSetDevice(c->devices[0]));
+            HIPCHK(hipEventRecord(c->ev_tile[0], rs[0]->stream)); // the root's receive
+            HIPCHK(hipStreamWaitEvent(c->root_stream, c->ev_tile[0], 0));
         } else {
             // the same device more than once (rehearsal): RCCL allows one rank per device, so the blocks move by device copies
             for (uint32_t i = 0; i < n; ++i) {
                 HIPCHK(hipSetDevice(c->devices[i]));
-                HIPCHK(hipStreamSynchronize(rs[i]->stream));
+                HIPCHK(hipEventRecord(c->ev_tile[i], rs[i]->stream));
             }
             HIPCHK(hipSetDevice(c->devices[0]));
             for (uint32_t i = 0; i < n; ++i) {
+                HIPCHK(hipStreamWaitEvent(c->root_stream, c->ev_tile[i], 0));
                 if (f32) HIPCHK(hipMemcpyAsync(c->d_gather_f32 + tile_px * i, rs[i]->d_f32, tile_px * 16, hipMemcpyDeviceToDevice, c->root_stream));
                 if (u8) HIPCHK(hipMemcpyAsync(c->d_gather_u8 + tile_px * i, rs[i]->d_u8, tile_px * 4, hipMemcpyDeviceToDevice, c->root_stream));
             }
@@ -1222,12 +1343,37 @@ int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t
         hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((frame_px + 255) / 256)), dim3(256), 0, c->root_stream, (uint32_t)W, (uint32_t)H, n, strip,
                            rows_max, f32 ? c->d_gather_f32 : nullptr, u8 ? c->d_gather_u8 : nullptr, c->d_full_f32, c->d_full_u8);
         HIPCHK(hipGetLastError());
-        if (rgba_f32) HIPCHK(hipMemcpyAsync(rgba_f32, c->d_full_f32, frame_px * 16, hipMemcpyDeviceToHost, c->root_stream));
-        if (rgba_u8) HIPCHK(hipMemcpyAsync(rgba_u8, c->d_full_u8, frame_px * 4, hipMemcpyDeviceToHost, c->root_stream));
-        HIPCHK(hipStreamSynchronize(c->root_stream));
+        HIPCHK(hipEventRecord(c->ev_frame, c->root_stream));
+        c->frame_recorded = true;
+        if (!c->use_rccl) { // device copies read the tiles from the root stream: a renderer's next frame must not overwrite its tile before
+            for (uint32_t i = 0; i < n; ++i) {
+                HIPCHK(hipSetDevice(c->devices[i]));
+                HIPCHK(hipStreamWaitEvent(rs[i]->stream, c->ev_frame, 0));
+            }
+            HIPCHK(hipSetDevice(c->devices[0]));
+        }
         return RT_OK;
     });
 }
+
+// Waits for the gather enqueued by rt_frame_gather_begin; copies the frame to the host where a pointer is given.
+int rt_comm_wait(rt_comm* c, float* rgba_f32, uint8_t* rgba_u8) {
+    if (!c) return fail(RT_ERR_INVALID, "null communicator");
+    if ((rgba_f32 && !c->gathered_f32) || (rgba_u8 && !c->gathered_u8)) return fail(RT_ERR_INVALID, "that plane was not gathered");
+    const size_t frame_px = (size_t)c->width * (size_t)c->height;
+    HIPCHK(hipSetDevice(c->devices[0]));
+    if (rgba_f32 && frame_px) HIPCHK(hipMemcpyAsync(rgba_f32, c->d_full_f32, frame_px * 16, hipMemcpyDeviceToHost, c->root_stream));
+    if (rgba_u8 && frame_px) HIPCHK(hipMemcpyAsync(rgba_u8, c->d_full_u8, frame_px * 4, hipMemcpyDeviceToHost, c->root_stream));
+    HIPCHK(hipStreamSynchronize(c->root_stream));
+    return RT_OK;
+}
+
+int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32, int want_device_u8) {
+    const int rc = rt_frame_gather_begin(c, rs, rgba_f32 || want_device_f32, rgba_u8 || want_device_u8);
+    return rc != RT_OK ? rc : rt_comm_wait(c, rgba_f32, rgba_u8);
+}
+
+int rt_comm_size(const rt_comm* c) { return c ? (int)c->devices.size() : 0; }
 
 } // extern "C"
 

@@ -88,6 +88,26 @@ class rt_scene_info_t(C.Structure):
     ]
 
 
+RT_SCHED_ALL_BOUNCES = 0xFFFFFFFF
+# kernel families of rt_stats.launches_by_kernel (include/rt_mi355x.h)
+KERNELS = {"megakernel": 0, "wf_init": 1, "wf_generate": 2, "wf_extend": 3, "wf_shade": 4, "wf_shade_reorder": 5, "wf_shade_matsort": 6,
+           "wf_finish": 7, "wf_finish_requeue": 8, "wf_tile_order": 9, "wf_resolve": 10, "fill_black": 11}
+RT_K_COUNT = 16
+
+
+class rt_schedule(C.Structure):
+    _fields_ = [
+        ("finish_depth", C.c_uint32),
+        ("samples_per_launch", C.c_uint32),
+        ("stream_lanes", C.c_uint32),
+        ("requeue", C.c_int32),
+        ("reorder", C.c_uint32),
+        ("matsort", C.c_uint32),
+        ("cost_order", C.c_int32),
+        ("hip_graph", C.c_uint32),
+    ]
+
+
 class rt_stats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64),
@@ -96,6 +116,11 @@ class rt_stats(C.Structure):
         ("hot_kernel_ms", C.c_double),
         ("hot_kernel_launches", C.c_uint32),
         ("launches", C.c_uint32),
+        ("launches_by_kernel", C.c_uint32 * RT_K_COUNT),
+        ("stream_lanes", C.c_uint32),
+        ("samples_per_launch", C.c_uint32),
+        ("finish_depth", C.c_uint32),
+        ("cost_ordered", C.c_uint32),
     ]
 
 
@@ -121,6 +146,8 @@ PROTOTYPES = {
     "rt_renderer_global_row": (C.c_int32, [C.c_void_p, C.c_int32]),
     "rt_renderer_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_renderer_set_russian_roulette": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_renderer_set_schedule": (C.c_int, [C.c_void_p, _P(rt_schedule)]),
+    "rt_renderer_get_schedule": (C.c_int, [C.c_void_p, _P(rt_schedule)]),
     "rt_render_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_render_frame_end": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_render_frame": (C.c_int, [C.c_void_p, _P(rt_camera), _P(C.c_float), _P(C.c_uint8), _P(rt_stats)]),
@@ -132,6 +159,9 @@ PROTOTYPES = {
     "rt_renderer_tile_f32": (C.c_void_p, [C.c_void_p]),
     "rt_renderer_tile_u8": (C.c_void_p, [C.c_void_p]),
     "rt_frame_gather": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_float), _P(C.c_uint8), C.c_int, C.c_int]),
+    "rt_frame_gather_begin": (C.c_int, [C.c_void_p, _P(C.c_void_p), C.c_int, C.c_int]),
+    "rt_comm_wait": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_uint8)]),
+    "rt_comm_size": (C.c_int, [C.c_void_p]),
     "rt_comm_frame_f32": (C.c_void_p, [C.c_void_p]),
     "rt_comm_frame_u8": (C.c_void_p, [C.c_void_p]),
     "rt_probe_xorshift": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, _P(C.c_float), _P(C.c_uint32)]),

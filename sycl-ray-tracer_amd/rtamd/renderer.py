@@ -99,6 +99,17 @@ class Frame:
     hot_kernel_ms: float
     hot_kernel_launches: int
     launches: int
+    kernels: dict = None         # launches of the frame per kernel family (abi.KERNELS): what actually ran
+    stream_lanes: int = 0        # the schedule as the library resolved it for this tile
+    samples_per_launch: int = 0
+    finish_depth: int = 0
+    cost_ordered: bool = False
+
+    @classmethod
+    def from_stats(cls, f, b, st):
+        return cls(f, b, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches), int(st.launches),
+                   {name: int(st.launches_by_kernel[i]) for name, i in abi.KERNELS.items()}, int(st.stream_lanes),
+                   int(st.samples_per_launch), int(st.finish_depth), bool(st.cost_ordered))
 
     def stat_lines(self) -> list[str]:
         """The three lines benchmark.py scrapes (src/render_wavefront.cpp:425-427, benchmark.py:49-55)."""
@@ -131,6 +142,20 @@ class IRenderer:
         """Extension (a to-do upstream: PLAN.md:23-27): paths are thinned from bounce `start_bounce` on; 0 = off (default)."""
         abi.check(self._lib.rt_renderer_set_russian_roulette(self.h, int(start_bounce)))
 
+    def set_schedule(self, finish_depth: int = 0, samples_per_launch: int = 0, stream_lanes: int = 0, requeue: int = -1,
+                     reorder: bool = False, matsort: bool = False, cost_order: int = -1, hip_graph: bool = False) -> None:
+        """rt_renderer_set_schedule: which of the wavefront renderer's schedules renders the frame (same frame bit for bit; the
+        reference has one: a launch per bounce, src/render_wavefront.cpp:396-417 = finish_depth=abi.RT_SCHED_ALL_BOUNCES).
+        Frame.kernels reports what ran. The megakernel ignores it."""
+        sc = abi.rt_schedule(int(finish_depth), int(samples_per_launch), int(stream_lanes), int(requeue), int(bool(reorder)),
+                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)))
+        abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)))
+
+    def get_schedule(self) -> abi.rt_schedule:
+        sc = abi.rt_schedule()
+        abi.check(self._lib.rt_renderer_get_schedule(self.h, C.byref(sc)))
+        return sc
+
     @property
     def local_rows(self) -> int:
         return int(self._lib.rt_renderer_local_rows(self.h))
@@ -147,16 +172,14 @@ class IRenderer:
         st = abi.rt_stats()
         abi.check(self._lib.rt_render_frame(self.h, C.byref(camera.c), abi.fptr(f) if want_f32 else None,
                                             abi.u8ptr(b) if want_u8 else None, C.byref(st)))
-        return Frame(f, b, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches),
-                     int(st.launches))
+        return Frame.from_stats(f, b, st)
 
     def render_frame_device(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> Frame:
         """Outputs go to DEVICE pointers (e.g. torch tensor .data_ptr()); nothing is copied to host."""
         st = abi.rt_stats()
         abi.check(self._lib.rt_render_frame_device(self.h, C.byref(camera.c), C.c_void_p(d_f32 or None),
                                                    C.c_void_p(d_u8 or None), C.c_void_p(stream or None), C.byref(st)))
-        return Frame(None, None, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches),
-                     int(st.launches))
+        return Frame.from_stats(None, None, st)
 
     def begin_frame(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> None:
         """Enqueues the frame and returns at once; collect it with end_frame(). Frames of different renderers overlap on
@@ -167,7 +190,7 @@ class IRenderer:
     def end_frame(self) -> Frame:
         st = abi.rt_stats()
         abi.check(self._lib.rt_render_frame_end(self.h, C.byref(st)))
-        return Frame(None, None, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches), int(st.launches))
+        return Frame.from_stats(None, None, st)
 
     def close(self):
         if self.h:
@@ -221,6 +244,24 @@ class TileComm:
         hs = (C.c_void_p * n)(*[r.h for r in renderers])
         abi.check(self._lib.rt_frame_gather(self.h, hs, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None, 0, 0))
         return f, b, rays
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.rt_comm_size(self.h))
+
+    def gather_begin(self, renderers, want_f32: bool = True, want_u8: bool = True) -> None:
+        """rt_frame_gather_begin: enqueues the gather of the renderers' collected frames (no host wait); the renderers may begin their
+        next frame right away."""
+        hs = (C.c_void_p * len(renderers))(*[r.h for r in renderers])
+        abi.check(self._lib.rt_frame_gather_begin(self.h, hs, int(want_f32), int(want_u8)))
+
+    def wait(self, shape, want_f32: bool = True, want_u8: bool = True):
+        """rt_comm_wait: blocks until the gathered frame is complete on the root device and returns host copies of it."""
+        h, w = shape
+        f = np.zeros((h, w, 4), np.float32) if want_f32 else None
+        b = np.zeros((h, w, 4), np.uint8) if want_u8 else None
+        abi.check(self._lib.rt_comm_wait(self.h, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None))
+        return f, b
 
     def close(self):
         if self.h:

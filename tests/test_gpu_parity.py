@@ -343,70 +343,118 @@ def test_megakernel_with_decoupled_shading_waves_keeps_the_frame(gpu_scenes, ora
         r.close()
 
 
+ALL_BOUNCES = abi.RT_SCHED_ALL_BOUNCES
+
+
+def _oracle_frame(oracle, sd, w, h, kind, depth, spp, **kw):
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    return oracle.OracleScene(sd).render(ocam, kind, depth, spp, **kw)
+
+
 @pytest.mark.parametrize("requeue", [1, 0])
 @pytest.mark.parametrize("samples_per_launch", [1, 2, 3, 5, 64])
-def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, monkeypatch, samples_per_launch, requeue):
-    """RT_WF_SAMPLES_PER_LAUNCH (with RT_WF_FINISH_DEPTH = 0): k_wf_finish renders that many samples of every pixel per launch instead
-    of one. requeue = 1 (default): the lane whose path has ended hands the pixel, with its RNG word, to a device-wide dynamic queue and
+def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, samples_per_launch, requeue):
+    """rt_schedule.samples_per_launch (finish_depth 0): k_wf_finish renders that many samples of every pixel per launch instead of all
+    of them. requeue = 1: the lane whose path has ended hands the pixel, with its RNG word, to a device-wide dynamic queue and
     any idle lane generates its next camera ray (breadth first); requeue = 0: the lane keeps the pixel and generates the next camera
     ray itself (depth first). 5 samples in chunks of 1, 2, 3, 5 and 64 (= all in one launch; 2 and 3 leave a shorter last chunk):
-    frame, unorm8 image and ray count equal the oracle's WavefrontRenderer, with Russian roulette and on an odd tile too."""
-    monkeypatch.setenv("RT_WF_FINISH_DEPTH", "0")
-    monkeypatch.setenv("RT_WF_REQUEUE", str(requeue))
-    monkeypatch.setenv("RT_WF_SAMPLES_PER_LAUNCH", str(samples_per_launch))
+    frame, unorm8 image and ray count equal the oracle's WavefrontRenderer, with Russian roulette and on an odd tile too — and the
+    launch counts the library reports are those of the schedule asked for."""
     for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 5), ("atrium", {"detail": 1}, (192, 108), 10, 5), ("cube", {}, (64, 40), 1, 5)):
         gs = gpu_scenes(name, **kw)
         sd = gs.desc
         cam = Camera.for_scene(sd, (w, h))
-        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
-        osc = oracle.OracleScene(sd)
+        use_bvh = name == "atrium"
         r = WavefrontRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(finish_depth=0, samples_per_launch=samples_per_launch, requeue=requeue)
         got = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        c = min(samples_per_launch, spp)
+        n_launches = -(-spp // c)
+        assert got.stream_lanes == 2 and got.samples_per_launch == c and got.finish_depth == 0
+        assert got.kernels["wf_finish"] == 2 * n_launches and got.kernels["wf_generate"] == 2 * n_launches
+        with_queue = sum(1 for s0 in range(0, spp, c) if min(c, spp - s0) > 1)  # launches that render more than one sample use the dynamic queue
+        assert got.kernels["wf_finish_requeue"] == (2 * with_queue if requeue else 0)
+        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == 0
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh)
         _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch}")
         again = r.render_frame(cam)
         _assert_frames_equal(again.rgba_f32, again.rgba_u8, again.rays, f, b, rays, f"{name} second frame")
         r.set_russian_roulette(2)
         got_rr = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rr_start=2)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rr_start=2)
         _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch} rr")
         r.set_russian_roulette(0)
         r.set_tile(1, 3, 8)
         tile = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=1, world=3, strip_rows=8)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rank=1, world=3, strip_rows=8)
         _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} samples_per_launch={samples_per_launch} tile 1/3")
         r.close()
 
 
-@pytest.mark.parametrize("env", [{"RT_WF_STREAMS": "2"}, {"RT_WF_STREAMS": "3"}, {"RT_WF_REQUEUE": "0"}, {"RT_WF_STREAMS": "1", "RT_WF_SAMPLES_PER_LAUNCH": "2"},
-                                 {"RT_WF_STREAMS": "4", "RT_WF_SAMPLES_PER_LAUNCH": "3", "RT_WF_REQUEUE": "1"}, {"RT_WF_FINISH_DEPTH": "2", "RT_WF_STREAMS": "1"}],
-                         ids=lambda e: ",".join(f"{k[6:].lower()}={v}" for k, v in e.items()))
-def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, monkeypatch, env):
-    """Any of the schedule's environment variables switches the wavefront renderer from its default (one launch per frame on one stream
-    lane) to the schedules with several launches: stream lanes x samples per launch x hand-over form x per-bounce depth. Whatever the
-    combination, frame, unorm8 image and ray count are the oracle's."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+SCHEDULES = [dict(samples_per_launch=1, stream_lanes=2), dict(samples_per_launch=1, stream_lanes=3), dict(samples_per_launch=1, requeue=0),
+             dict(stream_lanes=1, samples_per_launch=2), dict(stream_lanes=4, samples_per_launch=3, requeue=1), dict(finish_depth=2, stream_lanes=1),
+             dict(stream_lanes=2), dict(stream_lanes=3, cost_order=1), dict(finish_depth=ALL_BOUNCES, stream_lanes=1), dict(finish_depth=ALL_BOUNCES, hip_graph=True)]
+
+
+@pytest.mark.parametrize("sched", SCHEDULES, ids=lambda e: ",".join(f"{k}={v if v != ALL_BOUNCES else 'all'}" for k, v in e.items()))
+def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, sched):
+    """rt_renderer_set_schedule: stream lanes x samples per launch x hand-over form x per-bounce depth, in combination (one launch per
+    frame on several stream lanes included). Whatever the combination, frame, unorm8 image and ray count are the oracle's, and the
+    stats name the kernels that ran."""
     for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 5), ("atrium", {"detail": 1}, (200, 120), 10, 4)):
         gs = gpu_scenes(name, **kw)
         sd = gs.desc
         cam = Camera.for_scene(sd, (w, h))
-        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
-        osc = oracle.OracleScene(sd)
         r = WavefrontRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(**sched)
+        back = r.get_schedule()
+        assert all(getattr(back, k) == int(v) for k, v in sched.items())
         got = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
-        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {env}")
+        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else 2)
+        assert got.stream_lanes == lanes and got.finish_depth == min(sched.get("finish_depth", 0), depth)
+        assert got.kernels["wf_init"] == got.kernels["wf_resolve"] == lanes
+        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == lanes * spp * got.finish_depth
+        assert (got.kernels["wf_finish"] > 0) == (got.finish_depth < depth)
+        assert sum(got.kernels.values()) - got.kernels["wf_shade_reorder"] - got.kernels["wf_shade_matsort"] - got.kernels["wf_finish_requeue"] == got.launches
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {sched}")
         r.set_tile(2, 3, 8)
         tile = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=2, world=3, strip_rows=8)
-        _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} {env} tile 2/3")
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=2, world=3, strip_rows=8)
+        _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} {sched} tile 2/3")
         r.close()
 
 
-@pytest.mark.parametrize("finish_depth", [0, 1, 3, 7, 8, 99])
-def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, monkeypatch, finish_depth):
-    """The wavefront renderer's schedule: the first RT_WF_FINISH_DEPTH bounces launch by launch (EXTEND + SHADE with global
+def test_schedule_environment_shim_maps_onto_the_api(gpu_scenes, oracle, monkeypatch):
+    """The RT_WF_* environment variables (kept for scripts) only fill the initial rt_schedule at rt_renderer_create: the same
+    schedules run as through the API, and the stats say so."""
+    gs = gpu_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 96, 64, 6, 4
+    cam = Camera.for_scene(sd, (w, h))
+    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp)
+    cases = [({"RT_WF_FINISH_DEPTH": "99", "RT_WF_REORDER": "1"}, dict(finish_depth=99, reorder=1), ("wf_shade_reorder", 2 * spp * depth)),
+             ({"RT_WF_STREAMS": "3"}, dict(stream_lanes=3, samples_per_launch=1), ("wf_finish", 3 * spp)),
+             ({"RT_WF_REQUEUE": "0"}, dict(requeue=0, samples_per_launch=1), ("wf_finish", 2 * spp)),
+             ({"RT_WF_SAMPLES_PER_LAUNCH": "2"}, dict(samples_per_launch=2), ("wf_finish_requeue", 2 * 2)),
+             ({"RT_WF_LPT": "0"}, dict(cost_order=0), ("wf_finish", 1)), ({}, dict(finish_depth=0, samples_per_launch=0, stream_lanes=0), ("wf_finish", 1))]
+    for env, want, (kernel, count) in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = WavefrontRenderer(gs, (w, h), depth, spp)
+        for k in env:
+            monkeypatch.delenv(k)
+        sc = r.get_schedule()
+        assert all(getattr(sc, k) == v for k, v in want.items()), (env, {k: getattr(sc, k) for k in want})
+        got = r.render_frame(cam)
+        assert got.kernels[kernel] == count, (env, got.kernels)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"env {env}")
+        r.close()
+
+
+@pytest.mark.parametrize("finish_depth", [0, 1, 3, 7, 8, 99, ALL_BOUNCES])
+def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, finish_depth):
+    """The wavefront renderer's schedule: the first rt_schedule.finish_depth bounces launch by launch (EXTEND + SHADE with global
     compaction, as the reference's shoot_rays per bounce), then k_wf_finish follows the surviving rays to the end of their paths in
     one launch per sample. Every split — 0 (all in k_wf_finish), in between, >= max_depth (the reference's schedule) — must give the
     same frame, unorm8 image and ray count as the oracle's WavefrontRenderer, with and without Russian roulette, on full frames and
@@ -415,69 +463,104 @@ def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, monkeypatch,
         gs = gpu_scenes(name, **kw)
         sd = gs.desc
         cam = Camera.for_scene(sd, (w, h))
-        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
-        osc = oracle.OracleScene(sd)
-        monkeypatch.setenv("RT_WF_FINISH_DEPTH", str(finish_depth))  # read by rt_renderer_create
+        use_bvh = name != "cornell"
         r = WavefrontRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(finish_depth=finish_depth)
         got = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name != "cornell"))
+        d0 = min(finish_depth, depth)
+        lanes = 1 if finish_depth == 0 else 2
+        assert got.finish_depth == d0 and got.stream_lanes == lanes
+        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == lanes * spp * d0
+        assert got.kernels["wf_finish"] == (0 if d0 == depth else lanes * (spp if d0 else 1))
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh)
         _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} finish_depth={finish_depth}")
         r.set_russian_roulette(2)
         got_rr = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name != "cornell"), rr_start=2)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rr_start=2)
         _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, f, b, rays, f"{name} finish_depth={finish_depth} rr")
         r.set_russian_roulette(0)
         r.set_tile(2, 5, 8)
         tile = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name != "cornell"), rank=2, world=5, strip_rows=8)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rank=2, world=5, strip_rows=8)
         _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} finish_depth={finish_depth} tile 2/5")
         r.close()
     # max_depth 1: k_wf_finish (if it runs at all) only sees the last bounce
     gs = gpu_scenes("cube")
     sd = gs.desc
     r = WavefrontRenderer(gs, (64, 40), 1, 3)
+    r.set_schedule(finish_depth=finish_depth)
     got = r.render_frame(Camera.for_scene(sd, (64, 40)))
-    f, b, rays = oracle.OracleScene(sd).render(oracle.camera(64, 40, sd.camera.position, sd.camera.direction, sd.camera.focal_length),
-                                               abi.RT_RENDERER_WAVEFRONT, 1, 3)
+    f, b, rays = _oracle_frame(oracle, sd, 64, 40, abi.RT_RENDERER_WAVEFRONT, 1, 3)
     _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, "depth 1")
     r.close()
 
 
 @pytest.mark.parametrize("reorder,matsort", [(1, 0), (0, 1), (1, 1)])
-def test_wavefront_reordering_keeps_the_frame(gpu_scenes, oracle, monkeypatch, reorder, matsort):
-    """SURVEY §8f row f-3, ray re-ordering between bounces (RT_WF_REORDER: the compaction bins survivors by direction octant and
-    4x4x4 origin cell; RT_WF_MATSORT: SHADE partitions its rays by material kind): the queue order is not part of the result,
-    so frame, unorm8 image and ray count stay bit-identical to the default order and to the oracle — also with Russian roulette,
-    whose extra RNG draw sits between shading and compaction."""
+def test_wavefront_reordering_keeps_the_frame(gpu_scenes, oracle, reorder, matsort):
+    """SURVEY §8f row f-3, ray re-ordering between bounces (rt_schedule.reorder: the compaction bins survivors by direction octant and
+    4x4x4 origin cell; rt_schedule.matsort: SHADE partitions its rays by material kind). Both act in k_wf_shade, i.e. in the PER-BOUNCE
+    schedule (finish_depth = all bounces: EXTEND + SHADE launch pairs with compaction in between, the reference's shape,
+    src/render_wavefront.cpp:282-311) — which the test selects and then ASSERTS ran, from the launch counts the library reports: the
+    re-ordering variants of k_wf_shade were launched once per sample, bounce and stream lane. The queue order is not part of the result,
+    so frame, unorm8 image and ray count stay bit-identical to the oracle's — on both scenes, with Russian roulette (whose extra RNG
+    draw sits between shading and compaction) and on an odd tile (short queues, blocks that are not full)."""
     for name, kw, (w, h), depth, spp in (("cornell", {}, (96, 64), 8, 4), ("atrium", {"detail": 1}, (256, 144), 10, 3)):
         gs = gpu_scenes(name, **kw)
         sd = gs.desc
         cam = Camera.for_scene(sd, (w, h))
-        monkeypatch.delenv("RT_WF_REORDER", raising=False)
-        monkeypatch.delenv("RT_WF_MATSORT", raising=False)
-        base_r = WavefrontRenderer(gs, (w, h), depth, spp)
-        base = base_r.render_frame(cam)
-        base_r.set_russian_roulette(2)
-        base_rr = base_r.render_frame(cam)
-        base_r.close()
-        monkeypatch.setenv("RT_WF_REORDER", str(reorder))  # read by rt_renderer_create
-        monkeypatch.setenv("RT_WF_MATSORT", str(matsort))
+        use_bvh = name == "atrium"
         r = WavefrontRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(finish_depth=ALL_BOUNCES, reorder=reorder, matsort=matsort)
         got = r.render_frame(cam)
-        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, base.rgba_f32, base.rgba_u8, base.rays, f"{name} reorder={reorder} matsort={matsort}")
-        r.set_tile(1, 3, 8)  # an odd tile: short queues, blocks that are not full
+        pairs = got.stream_lanes * spp * depth
+        assert got.finish_depth == depth and got.kernels["wf_finish"] == 0, got.kernels
+        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == pairs
+        assert got.kernels["wf_shade_reorder"] == (pairs if reorder else 0) and got.kernels["wf_shade_matsort"] == (pairs if matsort else 0)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} reorder={reorder} matsort={matsort}")
+        r.set_tile(1, 3, 8)
         tile = r.render_frame(cam)
+        assert tile.kernels["wf_shade_reorder"] == (tile.stream_lanes * spp * depth if reorder else 0)
+        ft, bt, rt_ = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rank=1, world=3, strip_rows=8)
+        _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, ft, bt, rt_, f"{name} re-ordered tile 1/3")
         r.set_tile(0, 1, 8)
         r.set_russian_roulette(2)
         got_rr = r.render_frame(cam)
-        _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, base_rr.rgba_f32, base_rr.rgba_u8, base_rr.rays, f"{name} rr")
+        assert got_rr.kernels["wf_shade_matsort"] == (pairs if matsort else 0)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=use_bvh, rr_start=2)
+        _assert_frames_equal(got_rr.rgba_f32, got_rr.rgba_u8, got_rr.rays, f, b, rays, f"{name} re-ordered, roulette")
         r.close()
-        rows = [y for y in range(h) if (y // 8) % 3 == 1]
-        np.testing.assert_array_equal(tile.rgba_f32, base.rgba_f32[rows])
-        if name == "cornell":
-            f, b, rays = oracle.OracleScene(sd).render(oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length),
-                                                       abi.RT_RENDERER_WAVEFRONT, depth, spp)
-            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, "re-ordered wavefront vs oracle")
+
+
+@pytest.mark.parametrize("w,h,ordered", [(256, 144, True), (250, 144, False), (256, 140, False)])
+def test_cost_ordered_second_launch_keeps_the_frame(gpu_scenes, oracle, w, h, ordered):
+    """rt_schedule.cost_order = 1: sample 0 of every pixel in a launch of its own (recording what each path cost), the 8x8 blocks
+    sorted by that cost (k_wf_tile_cost, k_wf_order_tiles), the remaining samples with the most expensive blocks first. Automatic
+    selection only picks it for large frames at >= 32 spp; forced here on a small one, against cost_order = 0 and the oracle. A tile
+    that does not consist of whole 8x8 blocks falls back to queue order (and the stats say that it did)."""
+    for name, kw, depth, spp in (("cornell", {}, 8, 5), ("atrium", {"detail": 1}, 10, 3)):
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        r = WavefrontRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(cost_order=1)
+        on = r.render_frame(cam)
+        assert on.cost_ordered == ordered and on.kernels["wf_tile_order"] == (2 if ordered else 0)
+        assert on.kernels["wf_finish"] == on.kernels["wf_generate"] == (2 if ordered else 1)
+        r.set_schedule(cost_order=0)
+        off = r.render_frame(cam)
+        assert not off.cost_ordered and off.kernels["wf_finish"] == 1
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        _assert_frames_equal(on.rgba_f32, on.rgba_u8, on.rays, f, b, rays, f"{name} cost-ordered")
+        _assert_frames_equal(off.rgba_f32, off.rgba_u8, off.rays, f, b, rays, f"{name} queue order")
+        if ordered:  # a tile of the split keeps whole blocks (8-row strips): ordered too
+            r.set_schedule(cost_order=1)
+            r.set_tile(1, 2, 8)
+            t = r.render_frame(cam)
+            assert t.cost_ordered
+            ft, bt, rt_ = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=1, world=2, strip_rows=8)
+            _assert_frames_equal(t.rgba_f32, t.rgba_u8, t.rays, ft, bt, rt_, f"{name} cost-ordered tile")
+        r.close()
 
 
 @pytest.mark.parametrize("cls,kind", KINDS)
@@ -590,21 +673,23 @@ def test_full_size_properties(gpu_scenes, oracle, scene_cache, cls, kind):
         assert nbad == 0, f"strip {strip}: {nbad} pixels differ from the oracle (rmse {rmse:.3e})"
 
 
-def _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, got_f32, got_u8, strips, local_strip_of=lambda k: k, what=""):
-    """Bit-exact comparison of 8-row strips of a full-size GPU frame with the oracle. The oracle renders strip k alone as tile
+def _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, frames, strips, local_strip_of=lambda k: k, what=""):
+    """Bit-exact comparison of 8-row strips of full-size GPU frames with the oracle. The oracle renders strip k alone as tile
     (rank k, world n_strips) of the same frame at the SAME spp and depth (a pixel's RNG stream runs through all its samples,
-    so nothing can be reduced on one side only). `local_strip_of` maps a global strip index to its position in `got`."""
+    so nothing can be reduced on one side only) — once; `frames` = [(label, rgba_f32, rgba_u8), ...] are all compared with it.
+    `local_strip_of` maps a global strip index to its position in a frame."""
     osc = oracle.OracleScene(sd)
     ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
     n_strips = (h + 7) // 8
     for k in strips:
         f, b, _ = osc.render(ocam, kind, depth, spp, use_bvh=True, rank=k, world=n_strips, strip_rows=8)
         lk = local_strip_of(k)
-        gf, gb = got_f32[lk * 8: lk * 8 + f.shape[0]], got_u8[lk * 8: lk * 8 + f.shape[0]]
-        nbad = int((gf != f).any(-1).sum())
-        rmse = float(np.sqrt(np.mean((gf.astype(np.float64) - f) ** 2)))
-        assert nbad == 0, f"{what} strip {k}: {nbad} pixels differ from the oracle (rmse {rmse:.3e}, tolerance {RMSE_TOL})"
-        np.testing.assert_array_equal(gb, b)
+        for label, got_f32, got_u8 in frames:
+            gf, gb = got_f32[lk * 8: lk * 8 + f.shape[0]], got_u8[lk * 8: lk * 8 + f.shape[0]]
+            nbad = int((gf != f).any(-1).sum())
+            rmse = float(np.sqrt(np.mean((gf.astype(np.float64) - f) ** 2)))
+            assert nbad == 0, f"{what} [{label}] strip {k}: {nbad} pixels differ from the oracle (rmse {rmse:.3e}, tolerance {RMSE_TOL})"
+            np.testing.assert_array_equal(gb, b)
 
 
 # BASELINE.json configs 1-4 at their FULL sizes, both renderers where the config names both: size-independent properties
@@ -622,6 +707,9 @@ FULL_CONFIGS = [
 
 @pytest.mark.parametrize("name,kw,w,h,spp,depth,cls,strips", FULL_CONFIGS)
 def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, oracle, name, kw, w, h, spp, depth, cls, strips):
+    """... and for the wavefront renderer BOTH schedules at full size: the default (one k_wf_finish launch per frame) and the
+    per-bounce pipeline (k_wf_extend + k_wf_shade with __ballot / mbcnt compaction between bounces, the reference's shape:
+    src/render_wavefront.cpp:282-311) — asserted from the launch counts, whole frames bit-equal to each other, strips against the oracle."""
     sd = scene_cache(name, **kw)
     gs = gpu_scenes(name, **kw)
     kind = abi.RT_RENDERER_WAVEFRONT if cls is WavefrontRenderer else abi.RT_RENDERER_MEGAKERNEL
@@ -632,6 +720,9 @@ def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, oracle, name, kw
     assert np.isfinite(a.rgba_f32).all() and (a.rgba_f32[..., 3] == 1).all() and (a.rgba_f32[..., :3] >= 0).all()
     if cls is WavefrontRenderer:
         assert a.rgba_f32[..., :3].max() <= 1.0  # every sample is clamped to [0,1] before averaging
+        assert a.kernels["wf_finish"] >= 1 and a.kernels["wf_extend"] == 0 and a.samples_per_launch == spp  # the default: one launch per frame
+    else:
+        assert a.kernels["megakernel"] == 1
     np.testing.assert_array_equal(a.rgba_u8[..., :3], np.rint(np.clip(a.rgba_f32[..., :3], 0, 1) * 255).astype(np.uint8))
     # idempotence: the same renderer object renders the same frame again (all per-frame state is re-initialised)
     b = r.render_frame(cam, want_u8=False)
@@ -644,19 +735,32 @@ def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, oracle, name, kw
         fr = r.render_frame(cam, want_u8=False)
         parts.append(fr.rgba_f32)
         rays += fr.rays
-    r.close()
     assert rays == a.rays
     np.testing.assert_array_equal(assemble_tiles(parts, h, 2, 8), a.rgba_f32)
-    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, a.rgba_f32, a.rgba_u8, strips, what=f"{name} {w}x{h} {spp}spp {cls.__name__}")
+    frames = [("default schedule", a.rgba_f32, a.rgba_u8)]
+    if cls is WavefrontRenderer:
+        r.set_tile(0, 1, 8)
+        r.set_schedule(finish_depth=ALL_BOUNCES)
+        pb = r.render_frame(cam)
+        assert pb.finish_depth == depth and pb.kernels["wf_finish"] == 0
+        assert pb.kernels["wf_extend"] == pb.kernels["wf_shade"] == pb.stream_lanes * spp * depth
+        assert pb.rays == a.rays
+        np.testing.assert_array_equal(pb.rgba_f32, a.rgba_f32)
+        np.testing.assert_array_equal(pb.rgba_u8, a.rgba_u8)
+        frames.append(("per-bounce schedule", pb.rgba_f32, pb.rgba_u8))
+    r.close()
+    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, frames, strips, what=f"{name} {w}x{h} {spp}spp {cls.__name__}")
 
 
 @pytest.mark.parametrize("cls,kind", [(WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT), (MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL)])
 def test_config5_as_stated_tile_0_of_8(gpu_scenes, scene_cache, oracle, cls, kind):
     """BASELINE.json config 5 exactly as stated — atrium (detail 4, 283k triangles), 3840x2160, 256 spp, depth 16, the
     wavefront renderer with wave compaction (and the megakernel beside it), the tile ONE GPU of the 8-GPU split renders:
-    rank 0 of world 8, 8-row strips (34 strips, 272 rows, 1.04 M pixels, ~2.6 G rays). Properties of the whole tile plus
-    a bit-exact oracle comparison of two of its strips at the full 256 spp and depth 16 (nothing is reduced: ~70 M rays per
-    strip, some tens of seconds on the host cores)."""
+    rank 0 of world 8, 8-row strips (34 strips, 272 rows, 1.04 M pixels, ~3.1 G rays). "Wavefront w/ wave-compaction" is run in BOTH
+    of its forms: the default schedule (k_wf_finish: idle lanes refilled by __ballot / mbcnt ranks from the queue) and the per-bounce
+    pipeline (k_wf_extend + k_wf_shade, survivors compacted between bounces: 256 x 16 launch pairs per stream lane) — which kernels
+    ran is asserted from the library's launch counts. Properties of the whole tile plus a bit-exact oracle comparison of two of its
+    strips at the full 256 spp and depth 16 (nothing is reduced: ~70 M rays per strip, some tens of seconds on the host cores)."""
     sd = scene_cache("atrium", detail=4)
     gs = gpu_scenes("atrium", detail=4)
     w, h, spp, depth, world = 3840, 2160, 256, 16, 8
@@ -664,28 +768,38 @@ def test_config5_as_stated_tile_0_of_8(gpu_scenes, scene_cache, oracle, cls, kin
     r.set_tile(0, world, 8)
     rows = r.global_rows()
     assert len(rows) == 272 and all((y // 8) % world == 0 for y in rows)
-    a = r.render_frame(Camera.for_scene(sd, (w, h)))
-    r.close()
+    cam = Camera.for_scene(sd, (w, h))
+    a = r.render_frame(cam)
     n_px = len(rows) * w
     assert a.rgba_f32.shape == (272, w, 4)
     assert n_px * spp <= a.rays <= n_px * spp * depth
     assert 4.0 < a.rays / (n_px * spp) < 16.0  # enclosed scene: long paths
     assert np.isfinite(a.rgba_f32).all() and (a.rgba_f32[..., 3] == 1).all() and (a.rgba_f32[..., :3] >= 0).all()
+    frames = [("default schedule", a.rgba_f32, a.rgba_u8)]
     if cls is WavefrontRenderer:
         assert a.rgba_f32[..., :3].max() <= 1.0
+        assert a.kernels["wf_finish"] >= 1 and a.kernels["wf_extend"] == 0
+        r.set_schedule(finish_depth=ALL_BOUNCES)
+        pb = r.render_frame(cam)
+        assert pb.kernels["wf_finish"] == 0 and pb.kernels["wf_extend"] == pb.kernels["wf_shade"] == pb.stream_lanes * spp * depth
+        assert pb.rays == a.rays
+        np.testing.assert_array_equal(pb.rgba_f32, a.rgba_f32)
+        frames.append(("per-bounce schedule", pb.rgba_f32, pb.rgba_u8))
+    r.close()
     np.testing.assert_array_equal(a.rgba_u8[..., :3], np.rint(np.clip(a.rgba_f32[..., :3], 0, 1) * 255).astype(np.uint8))
     # global strips 64 and 200 belong to rank 0 (64 % 8 == 200 % 8 == 0) and are its local strips 8 and 25
-    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, a.rgba_f32, a.rgba_u8, (64, 200), local_strip_of=lambda k: k // world,
+    _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, frames, (64, 200), local_strip_of=lambda k: k // world,
                                     what=f"config 5 {cls.__name__}")
 
 
 @pytest.mark.parametrize("bvh", [abi.RT_BVH_SAH, abi.RT_BVH_LBVH, abi.RT_BVH_LBVH_GPU])
 def test_far_away_ray_origins_equal_brute_force(oracle, scene_cache, bvh):
-    """Ray origins up to 100 scene diameters away from the scene (the documented range of the closest-hit contract: the padding of
+    """Ray origins up to 100 scene extents away from the scene (inside the enforced range of the closest-hit contract: the padding of
     the boxes, 2e-5 x scene scale, covers fp32 rounding of the slab arithmetic for origins that far) on exact
     diagonals through the cube's corners and centre — equal slab distances on all three axes, the configuration in which an
-    ABSENT child's inverted box is closest to testing as a hit (the kernel tests slots 1..3 for kChildEmpty explicitly)
-    — and on random far origins, against the CPU brute force."""
+    ABSENT child's inverted box (qlo = 255 > qhi = 0) is closest to testing as a hit: the inner step relies on the inversion alone
+    and has no explicit kChildEmpty test, which is sound inside the contract's range — and on random far origins, against the CPU
+    brute force. (Beyond the range the entry points refuse: test_contract_range_is_enforced.)"""
     sd = scene_cache("cube")
     gs, osc = Scene(sd, 0, bvh), oracle.OracleScene(sd)
     tw = sd.world_triangles().reshape(-1, 3)
@@ -714,6 +828,99 @@ def test_far_away_ray_origins_equal_brute_force(oracle, scene_cache, bvh):
     np.testing.assert_array_equal(gv, ev)
     assert (gtri != NO_TRI).sum() > 100
     gs.close()
+
+
+def test_contract_range_is_enforced(gpu_scenes, oracle, scene_cache):
+    """Both sides of the limit of the closest-hit contract (include/rt_mi355x.h: origins at most 100 scene scales outside the scene's
+    bounds on any axis; src/trace_ray.hpp:18-27 states none, so the narrowing must not be silent). Just inside: answered, and equal
+    to the brute force. Just outside, or not finite: RT_ERR_INVALID naming the ray — for rt_intersect_batch and, through the camera
+    centre, for both renderers."""
+    sd = scene_cache("cube")
+    gs, osc = gpu_scenes("cube"), oracle.OracleScene(sd)
+    info = gs.info()
+    lo, hi = np.array(info.bounds_lo, np.float64), np.array(info.bounds_hi, np.float64)
+    scale = max(float((hi - lo).max()), float(np.abs(np.concatenate([lo, hi])).max()))
+    c = (lo + hi) / 2
+    axes = np.concatenate([np.eye(3), -np.eye(3)])
+    inside = np.array([np.where(a > 0, hi, np.where(a < 0, lo, c)) + a * 99.5 * scale for a in axes], np.float32)
+    outside = np.array([np.where(a > 0, hi, np.where(a < 0, lo, c)) + a * 100.5 * scale for a in axes], np.float32)
+    dirs = (-axes).astype(np.float32)  # straight back at the cube
+    g = gs.intersect(inside, dirs)
+    e = osc.intersect(inside, dirs, use_bvh=False)
+    for x, y in zip(g, e):
+        np.testing.assert_array_equal(x, y)
+    assert (g[3] != NO_TRI).all()
+    for k in range(6):
+        org = inside.copy()
+        org[k] = outside[k]
+        with pytest.raises(abi.RtError, match=f"ray {k}: origin more than 100 scene scales"):
+            gs.intersect(org, dirs)
+    bad = inside.copy()
+    bad[2, 1] = np.nan
+    with pytest.raises(abi.RtError, match="ray 2"):
+        gs.intersect(bad, dirs)
+    w, h = 32, 24
+    for cls, kind in KINDS:
+        r = cls(gs, (w, h), 4, 2)
+        near = r.render_frame(Camera((w, h), tuple(inside[2]), tuple(dirs[2]), 200.0))  # +z side, looking back: a narrow view of the cube
+        ocam = oracle.camera(w, h, tuple(inside[2]), tuple(dirs[2]), 200.0)
+        f, b, rays = osc.render(ocam, kind, 4, 2, use_bvh=False)
+        _assert_frames_equal(near.rgba_f32, near.rgba_u8, near.rays, f, b, rays, f"camera at 99.5 scales {cls.__name__}")
+        assert rays > w * h * 2  # it does see the cube
+        with pytest.raises(abi.RtError, match="camera lies more than 100 scene scales"):
+            r.render_frame(Camera((w, h), tuple(outside[2]), tuple(dirs[2]), 200.0))
+        again = r.render_frame(Camera((w, h), tuple(inside[2]), tuple(dirs[2]), 200.0))  # the refusal leaves the renderer usable
+        assert again.rays == rays
+        r.close()
+
+
+def test_gather_overlaps_with_the_next_frame(gpu_scenes, oracle):
+    """rt_frame_gather_begin / rt_comm_wait: the gather of frame N is only ENQUEUED (event waits between the renderers' streams and the
+    root's, no host wait), frame N+1 is begun on every renderer right behind it, and frame N is collected afterwards — every frame that
+    comes back is the single-device frame, for a moving camera (so that a frame overwritten too early would show), on the RCCL path
+    (one rank) and on the device-copy path (three tiles on one device)."""
+    gs = gpu_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 120, 93, 5, 2
+    poses = [tuple(np.asarray(sd.camera.position) + np.array([0.15 * i, -0.05 * i, 0.1 * i])) for i in range(4)]
+    cams = [Camera((w, h), p, sd.camera.direction, sd.camera.focal_length) for p in poses]
+    ref = WavefrontRenderer(gs, (w, h), depth, spp)
+    want = [ref.render_frame(c) for c in cams]
+    ref.close()
+    assert not np.array_equal(want[0].rgba_f32, want[1].rgba_f32)
+    for devices in ((0,), (0, 0, 0)):
+        comm = TileComm(devices)
+        n = len(devices)
+        assert comm.size == n
+        rs = []
+        for k in range(n):
+            r = WavefrontRenderer(gs, (w, h), depth, spp)
+            r.set_tile(k, n, 8)
+            rs.append(r)
+        lib = abi.load_library()
+
+        def begin(cam):
+            for r in rs:
+                r.begin_frame(cam, d_f32=lib.rt_renderer_tile_f32(r.h), d_u8=lib.rt_renderer_tile_u8(r.h))
+
+        begin(cams[0])
+        for i in range(len(cams)):
+            rays = sum(r.end_frame().rays for r in rs)
+            comm.gather_begin(rs)
+            if i + 1 < len(cams):
+                begin(cams[i + 1])  # in flight while frame i is gathered and copied out
+            f, b = comm.wait((h, w))
+            assert rays == want[i].rays
+            np.testing.assert_array_equal(f, want[i].rgba_f32)
+            np.testing.assert_array_equal(b, want[i].rgba_u8)
+        comm.gather_begin(rs, want_f32=False)  # only the u8 plane this time: asking rt_comm_wait for the other one is an error, not stale data
+        with pytest.raises(abi.RtError, match="not gathered"):
+            comm.wait((h, w), want_f32=True, want_u8=True)
+        _, b = comm.wait((h, w), want_f32=False)
+        np.testing.assert_array_equal(b, want[-1].rgba_u8)
+        for r in rs:
+            r.close()
+        comm.close()
 
 
 def _soup_scene(rng, n_tris, scale=1.0, offset=(0, 0, 0), duplicates=0, degenerate=0, n_inst=3):

@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol(rtlib):
     for n in names:
         assert hasattr(rtlib, n), f"librt_mi355x.so does not export {n}"
         assert n in abi.PROTOTYPES, f"{n} has no ctypes prototype in rtamd/abi.py"
-    assert rtlib.rt_abi_version() == 4
+    assert rtlib.rt_abi_version() == 5
 
 
 def test_struct_layouts_match_header(tmp_path):
     """ctypes mirrors vs the real header, measured by compiling a C program against include/rt_mi355x.h."""
     import subprocess
-    names = ["rt_camera", "rt_material", "rt_instance", "rt_scene_desc", "rt_scene_info_t", "rt_stats"]
+    names = ["rt_camera", "rt_material", "rt_instance", "rt_scene_desc", "rt_scene_info_t", "rt_stats", "rt_schedule"]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "rt_mi355x.h"\nint main(void){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
@@ -41,6 +41,11 @@ def test_struct_layouts_match_header(tmp_path):
     for n, sz in zip(names, sizes):
         assert C.sizeof(getattr(abi, n)) == sz, n
     assert sizes[:3] == [56, 44, 104]
+    # the kernel-family indices of rt_stats.launches_by_kernel are the header's enum values
+    text = (REPO / "include" / "rt_mi355x.h").read_text()
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"RT_K_([A-Z_]+) = (\d+)", text)}
+    assert enum.pop("count") == abi.RT_K_COUNT
+    assert enum == abi.KERNELS
 
 
 def _host_scene(rtlib, sd, bvh=abi.RT_BVH_DEFAULT):
@@ -152,6 +157,10 @@ def test_gpu_entry_points_fail_loudly_without_a_device(rtlib, scene_cache):
     devs = (C.c_int * 2)(0, 1)
     assert rtlib.rt_comm_create(2, devs, C.byref(comm)) == abi.RT_ERR_NO_DEVICE and not comm.value
     assert rtlib.rt_frame_gather(None, None, None, None, 1, 1) == abi.RT_ERR_INVALID
+    assert rtlib.rt_frame_gather_begin(None, None, 1, 1) == abi.RT_ERR_INVALID and rtlib.rt_comm_wait(None, None, None) == abi.RT_ERR_INVALID
+    assert rtlib.rt_comm_size(None) == 0
+    sc = abi.rt_schedule()
+    assert rtlib.rt_renderer_set_schedule(None, C.byref(sc)) == abi.RT_ERR_INVALID and rtlib.rt_renderer_get_schedule(None, C.byref(sc)) == abi.RT_ERR_INVALID
     assert rtlib.rt_renderer_tile_f32(None) is None and rtlib.rt_comm_frame_u8(None) is None and rtlib.rt_comm_uses_rccl(None) == 0
     rtlib.rt_comm_destroy(None)
     rtlib.rt_scene_destroy(hs)
