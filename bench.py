@@ -7,19 +7,32 @@ k with k % N == r of the SAME frame (strong scaling: total work is fixed), then 
 are gathered to rank 0 over xGMI and de-interleaved there. Scene, BVH and ray queues are resident in HBM
 before the timed region; the frame stays on the device (no PCIe traffic inside the timed region).
 
-Both renderers of the path (wavefront, megakernel) are measured with the same K steps; the headline `value` is the
-faster one (`config.renderer`), `renderers` holds both with their rooflines.
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES ITS OWN RANKS: before anything touches the
+GPU (this process never imports torch) it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py` as
+a child process, relays its JSON line and exits with its code. Under an external launcher (WORLD_SIZE set) it is one rank.
+
+Three renderers of the path are measured with the same K steps:
+  wavefront             the WavefrontRenderer's default schedule: one k_wf_generate + one k_wf_finish launch per frame
+  megakernel            the MegakernelRenderer
+  wavefront_per_bounce  the WavefrontRenderer in the reference's shape (src/render_wavefront.cpp:396-417): per sample and bounce one
+                        k_wf_extend + one k_wf_shade launch, survivors compacted between bounces with __ballot / mbcnt ranks
+The headline `value` is the fastest (`config.renderer`); `renderers` holds all three with their rooflines.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak (the
                  contractual figure: tiny by construction for a traversal kernel), `traffic` = FETCH_SIZE + WRITE_SIZE of that
-                 kernel, and `binding` = the bound that actually binds: VALU issue cycles against the ceiling measured for the
-                 kernel's own instruction mix (profiles/r02_valu_calibration.json). traffic and binding are MEASURED IN THIS RUN
-                 (N = 1): after the timed region bench.py renders one more frame of the same configuration in a child process
-                 under `rocprofv3 --pmc` (three passes: FETCH_SIZE+TCC_HIT, WRITE_SIZE+TCC_MISS, SQ VALU counters); if rocprofv3
-                 is not usable they fall back to the committed profiles/ files and say so in `source`.
+                 kernel, and `binding` = the bound that actually binds, MEASURED: VALU issue busy = 4 x (SQ_ACTIVE_INST_VALU -
+                 SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel cycles) — counters of the product build in this very run, no model
+                 (semantics pinned on known instruction streams: profiles/r03_valu_calibration2.json). traffic and binding are
+                 measured at N = 1: after the timed region one more frame per renderer is rendered in a child process under
+                 `rocprofv3 --pmc`, one pass per counter group (counters only).
   cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+For N > 1 the line also carries `per_rank_ms` (every rank's own time for the K frames), `gather_ms` (rank 0's mean time in the
+gather + de-interleave per frame) and `rccl_ranks` (an all-reduce of ones over the process group: what RCCL saw).
+
+Rehearsal without GPUs (tests/test_multi_gloo.py): `--backend gloo --rehearsal-tiles DIR` — the launcher, the process group, the
+gather, the de-interleave and the JSON line run on the CPU with tiles read from DIR/tile_<rank>.npy instead of rendered ones.
 """
 from __future__ import annotations
 
@@ -29,6 +42,7 @@ import glob
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -41,28 +55,30 @@ sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Algorithmic bytes per traced ray. SURVEY.md §8(d) prices the reference's single shoot kernel at
-# 76 B/ray (34 B state read + 8 B RNG r/w + 34 B state write). Here that kernel is split in two:
-#   k_wf_extend (dominant, ~78 % of the frame): reads org+id 16 B + dir 8 B, writes the hit record 16 B  = 40 B/ray
-#   k_wf_shade                                : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B = 92 B/ray
+# 76 B/ray (34 B state read + 8 B RNG r/w + 34 B state write). In the per-bounce schedule that kernel is split in two:
+#   k_wf_extend (dominant in time): reads org+id 16 B + dir 8 B, writes the hit record 16 B                          = 40 B/ray
+#   k_wf_shade                    : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B                = 92 B/ray
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
-# The wavefront renderer's default schedule (RT_WF_FINISH_DEPTH=0): one compacted queue per sample, written by
-# k_wf_generate (34 B state + 4 B RNG r/w + count) and consumed by k_wf_finish, which follows every path to its end in registers:
+# The wavefront renderer's default schedule: one queue per frame, written by k_wf_generate (34 B state + 4 B RNG r/w)
+# and consumed by k_wf_finish, which follows every path to its end in registers:
 #   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
 FINISH_BYTES_PER_PATH = 74
 MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel per frame (the timed region stores no RGBA8 image)
 # SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 48-B triangle records, 124 B of hit shading;
-# the per-ray counts are the atrium's, measured with RT_KERNEL_STATS=1 (gpurun_out/r02/stats_base.log): 17.10 nodes, 4.60 triangles
+# per-ray counts of the atrium measured with RT_KERNEL_STATS=1: 17.10 nodes, 4.60 triangles
 TRAVERSAL_BYTES_PER_RAY = 17.10 * 64 + 4.60 * 48 + 124
+N_SIMDS = 1024                   # 256 CUs x 4
+RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce")
 
 
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--renderer", choices=["auto", "wavefront", "megakernel"], default=os.environ.get("RT_BENCH_RENDERER", "auto"),
-                    help="auto = measure both renderers of the path, headline the faster one")
+    ap.add_argument("--renderer", choices=["auto", *RENDERERS], default=os.environ.get("RT_BENCH_RENDERER", "auto"),
+                    help="auto = measure all renderers of the path, headline the fastest")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
@@ -76,29 +92,56 @@ def main() -> int:
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-frames-in-flight measurement")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes after the timed region")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # one frame, no timing: the process rocprofv3 wraps
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: CPU rehearsal of the multi-rank path (needs --rehearsal-tiles)")
+    ap.add_argument("--rehearsal-tiles", default=None, help="directory with tile_<rank>.npy (rows x W x 4 float32): used INSTEAD of rendering")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 writes the last gathered frame here (.npy)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)  # comma-separated renderers: one untimed frame each, the process rocprofv3 wraps
+    return ap.parse_args(argv)
+
+
+# ---- the launcher: N > 1 without an external one ----------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """Starts N ranks of this script with torch.distributed.run as a CHILD process (never an exec: nothing in this process has touched
+    the GPU, and nothing will). Returns the child's exit code; its stdout (the JSON line of rank 0) is passed through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def main() -> int:
+    args = parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)  # before any torch / HIP call in this process
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from rtamd import abi, scenes
-    from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
+    from rtamd.dist import FrameGatherer
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # RT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, gather, all-reduces) even with one
-    # rank — a one-GPU rehearsal of what the N > 1 runs execute
+    rehearsal = args.backend == "gloo"
+    if rehearsal and not args.rehearsal_tiles:
+        raise SystemExit("--backend gloo is the CPU rehearsal of the multi-rank path: give --rehearsal-tiles DIR (there is no CPU renderer)")
+    if rehearsal:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    # RT_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, gather, all-reduces) even with one rank
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
     if use_dist:
         if world == 1:
@@ -106,13 +149,12 @@ def main() -> int:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, strip = args.width, args.height, 8
-    sd = scenes.atrium_scene(args.detail)
-    scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
-    cam = Camera.for_scene(sd, (W, H))
-    from rtamd.dist import FrameGatherer
     F0 = max(1, args.frames_in_flight)
     fgs = [FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist) for _ in range(max(F0, 2))]  # one strip buffer per frame in flight
     fg = fgs[0]
@@ -120,27 +162,64 @@ def main() -> int:
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
+
+    # what RCCL (gloo in the rehearsal) saw: every rank contributes a one
+    comm_ranks = 1
+    if use_dist:
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        comm_ranks = int(ones.item())
+
+    if rehearsal:
+        tile = torch.from_numpy(np.load(Path(args.rehearsal_tiles) / f"tile_{rank}.npy"))
+        assert tile.shape[0] == fg.rows and tile.shape[1] == W, (tile.shape, fg.rows, W)
+        scene = sd = cam = None
+    else:
+        from rtamd import abi, scenes
+        from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
+        sd = scenes.atrium_scene(args.detail)
+        scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+        cam = Camera.for_scene(sd, (W, H))
+
+    def make_renderer(name):
+        cls = MegakernelRenderer if name == "megakernel" else WavefrontRenderer
+        r = cls(scene, (W, H), args.depth, args.spp)
+        if name == "wavefront_per_bounce":
+            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES)
+        r.set_tile(rank, world, strip)
+        r.set_profiling(True)  # per-launch hipEvents of the traversal / shading kernels, on the launches' own streams
+        return r
 
     def measure(name, F=F0):
-        """W warm-up frames, then exactly K timed frames of one renderer: render this rank's strips, RCCL gather,
-        de-interleave on rank 0; barrier + synchronize on both sides; MAX over ranks of the time, SUM of the rays."""
-        cls = WavefrontRenderer if name == "wavefront" else MegakernelRenderer
-        rs = [cls(scene, (W, H), args.depth, args.spp) for _ in range(F)]
-        for r in rs:
-            r.set_tile(rank, world, strip)
-            r.set_profiling(True)  # per-launch hipEvents of the dominant kernel, on the launch's own stream
-        assert fg.rows == rs[0].local_rows
-        tot = {"rays": 0, "hot_ms": 0.0, "hot_launches": 0, "dev_ms": 0.0}
+        """W warm-up frames, then exactly K timed frames of one renderer: render this rank's strips, gather (RCCL), de-interleave on
+        rank 0; barrier + synchronize on both sides; MAX over ranks of the time, SUM of the rays."""
+        rs = [] if rehearsal else [make_renderer(name) for _ in range(F)]
+        if rs:
+            assert fg.rows == rs[0].local_rows
+        tot = {"rays": 0, "hot_ms": 0.0, "hot_launches": 0, "dev_ms": 0.0, "gather_s": 0.0, "kernel_ms": {}, "kernels": {}, "lanes": 0}
 
         def collect(k):
-            """wait for frame buffer k's frame, gather it (RCCL gather of the per-GPU strip buffers + de-interleave on rank 0)"""
-            fr = rs[k].end_frame()
+            """wait for frame buffer k's frame, gather it (gather of the per-GPU strip buffers + de-interleave on rank 0)"""
+            if rehearsal:
+                fgs[k].local[: tile.shape[0]].copy_(tile)
+                rays = 0
+            else:
+                fr = rs[k].end_frame()
+                rays = fr.rays
+                tot["hot_ms"] += fr.hot_kernel_ms
+                tot["hot_launches"] += fr.hot_kernel_launches
+                tot["dev_ms"] += fr.device_ms
+                tot["lanes"] = fr.stream_lanes
+                for kn, v in fr.kernel_ms.items():
+                    tot["kernel_ms"][kn] = tot["kernel_ms"].get(kn, 0.0) + v
+                for kn, v in fr.kernels.items():
+                    tot["kernels"][kn] = tot["kernels"].get(kn, 0) + v
+            t = time.perf_counter()
             fgs[k].gather()
-            tot["rays"] += fr.rays
-            tot["hot_ms"] += fr.hot_kernel_ms
-            tot["hot_launches"] += fr.hot_kernel_launches
-            tot["dev_ms"] += fr.device_ms
+            tot["gather_s"] += time.perf_counter() - t
+            tot["rays"] += rays
 
         def run(n):
             """n frames; with --frames-in-flight F > 1 frame i+1..i+F-1 are already enqueued (each in its own renderer and
@@ -150,85 +229,69 @@ def main() -> int:
                 k = i % F
                 if len(queue) == F:
                     collect(queue.pop(0))
-                rs[k].begin_frame(cam, d_f32=fgs[k].local.data_ptr())
+                if not rehearsal:
+                    rs[k].begin_frame(cam, d_f32=fgs[k].local.data_ptr())
                 queue.append(k)
             while queue:
                 collect(queue.pop(0))
 
         run(args.warmup)
         barrier()
-        for key in tot:
-            tot[key] = 0
+        tot.update(rays=0, hot_ms=0.0, hot_launches=0, dev_ms=0.0, gather_s=0.0, kernel_ms={}, kernels={})
         t0 = time.perf_counter()
         run(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        rays, hot_ms, hot_launches, dev_ms = tot["rays"], tot["hot_ms"], tot["hot_launches"], tot["dev_ms"]
-        rows = rs[0].local_rows
+        rows = fg.rows
         for r in rs:
             r.close()
-        rays_all = float(rays)
+        rays_all, own_ms = float(tot["rays"]), elapsed * 1e3
+        per_rank_ms = [round(own_ms, 3)]
         if use_dist:
             mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            sm = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+            sm = torch.tensor([float(tot["rays"])], dtype=torch.float64, device=dev)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-            elapsed, rays_all = float(mx[0]), float(sm[0])
-        # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch time
-        finish_depth = int(os.environ.get("RT_WF_FINISH_DEPTH", "0"))
-        if name == "wavefront" and finish_depth < args.depth:  # the profiled launches are k_wf_finish: one per sample and stream lane
-            kernel, bytes_per_launch = "k_wf_finish", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
-        elif name == "wavefront":
-            kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
-        else:
-            kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
-        mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
-        achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": hot_launches,
-                "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1)}
-        if name == "wavefront":
-            if kernel == "k_wf_extend":
-                frame_bytes = (EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / args.steps
-                roof["frame_bytes_per_ray"] = EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
-                roof["frame_achieved_gbs"] = round(frame_bytes / (elapsed / args.steps) / 1e9, 3)  # whole path, all kernels
-            else:
-                roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
-                per_lane = max(hot_launches, 1) / max(args.steps, 1)
-                roof["schedule"] = (f"RT_WF_FINISH_DEPTH={finish_depth}: generate -> compacted queue -> k_wf_finish, {per_lane:g} launches per frame "
-                                    f"for {args.spp} samples (the library picks samples per launch and stream lanes by tile size: DESIGN.md §5)")
-            roof["concurrent_streams"] = int(os.environ.get("RT_WF_STREAMS", "2"))  # sub-tiles on streams of their own share the chip (1 in the chain regime)
-            roof["note"] = "incoherent BVH traversal is bound by VALU issue at its lane utilisation; the HBM fraction is small by construction (DESIGN.md §6)"
-        else:
-            roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache
-            roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
-            roof["note"] = ("the megakernel has no per-ray HBM stream (SURVEY.md §8d): its only algorithmic HBM traffic is the frame store; "
-                            "its BVH gathers are served by L2 / Infinity Cache (profiles/r01_traffic.json)")
-        return {"renderer": name, "value": round(rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
-                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "rays_per_frame": int(rays_all / args.steps),
-                "device_ms_per_step": round(dev_ms / args.steps, 3), "roofline": roof}
+            each = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(each, torch.tensor([own_ms], dtype=torch.float64, device=dev))
+            elapsed, rays_all, per_rank_ms = float(mx[0]), float(sm[0]), [round(float(e[0]), 3) for e in each]
+        res = {"renderer": name, "value": round(rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "rays_per_frame": int(rays_all / args.steps),
+               "device_ms_per_step": round(tot["dev_ms"] / args.steps, 3),
+               "per_rank_ms": per_rank_ms, "gather_ms": round(tot["gather_s"] / args.steps * 1e3, 3)}
+        if not rehearsal:
+            res["launches_per_frame"] = {k: v // args.steps for k, v in tot["kernels"].items() if v}
+            res["roofline"] = roofline_of(name, args, tot, rows, W, rays_all, elapsed)
+        return res
 
-    names = ["wavefront", "megakernel"] if args.renderer == "auto" else [args.renderer]
-    results = [measure(n) for n in names]
-    # for information only, never the headline: the same renderer with two frames in flight
-    lead = max(results, key=lambda d: d["value"])["renderer"] if rank == 0 else None
-    if use_dist:
-        box = [lead]
-        dist.broadcast_object_list(box, src=0)
-        lead = box[0]
-    pipelined = measure(lead, 2) if F0 == 1 and not args.no_pipelined else None
+    if rehearsal:
+        results = [measure("rehearsal")]
+        lead, pipelined = "rehearsal", None
+    else:
+        names = list(RENDERERS) if args.renderer == "auto" else [args.renderer]
+        results = [measure(n) for n in names]
+        # for information only, never the headline: the same renderer with two frames in flight
+        lead = max(results, key=lambda d: d["value"])["renderer"] if rank == 0 else None
+        if use_dist:
+            box = [lead]
+            dist.broadcast_object_list(box, src=0)
+            lead = box[0]
+        pipelined = measure(lead, 2) if F0 == 1 and not args.no_pipelined else None
 
     if rank == 0:
-        best = max(results, key=lambda d: d["value"])  # headline: the faster of the path's two renderers
+        best = max(results, key=lambda d: d["value"])  # headline: the fastest of the path's renderers
+        workload = (f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}" if not rehearsal
+                    else f"REHEARSAL (no rendering: tiles from files) {W}x{H}")
         out = {
             "metric": "Mrays/s", "value": best["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": best["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}",
-                       "renderer": best["renderer"], "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}", "frames_in_flight": F0,
-                       "rays_per_frame": best["rays_per_frame"]},
-            "roofline": best["roofline"],
+            "config": {"workload": workload, "renderer": best["renderer"], "bvh": args.bvh, "tile_split": f"{strip}-row strips, rank = strip % {world}",
+                       "frames_in_flight": F0, "rays_per_frame": best["rays_per_frame"]},
+            "roofline": best.get("roofline"),
             "device_ms_per_step": best["device_ms_per_step"],
+            "per_rank_ms": best["per_rank_ms"], "gather_ms": best["gather_ms"],
+            "rccl_ranks": comm_ranks, "backend": args.backend if use_dist else None,
             "renderers": {d["renderer"]: d for d in results},
         }
         if pipelined:
@@ -236,124 +299,204 @@ def main() -> int:
                                            "ms_per_step": pipelined["ms_per_step"],
                                            "note": "same K frames with the next frame enqueued (second renderer + strip buffer) before the "
                                                    "current one is collected; not the headline: ms_per_step is then no longer one frame's latency"}
-        if world == 1:
-            attach_pmc(out["roofline"], best, args)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not rehearsal:
+            attach_pmc(out, args)
+        if world == 1 and not rehearsal and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
+        if args.dump_frame:
+            np.save(args.dump_frame, fg.frame.cpu().numpy())
         print(json.dumps(out), flush=True)
-    scene.close()
+    if scene is not None:
+        scene.close()
     if use_dist:
         dist.destroy_process_group()
     return 0
 
 
+def roofline_of(name, args, tot, rows, W, rays_all, elapsed):
+    """The contractual roofline object of one renderer on THIS rank: algorithmic bytes per launch of its dominant kernel / that
+    kernel's mean launch duration (hipEvents on the launch's own stream) against the HBM peak."""
+    hot_launches, hot_ms = tot["hot_launches"], tot["hot_ms"]
+    rays = tot["rays"]
+    if name == "wavefront":
+        kernel, bytes_per_launch = "k_wf_finish", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
+    elif name == "wavefront_per_bounce":
+        kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
+    else:
+        kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
+    mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
+    achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": hot_launches,
+            "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1)}
+    if name == "wavefront_per_bounce":
+        # both kernels of the pipeline, each against its own algorithmic bytes; the launches of the two stream lanes overlap, so the
+        # per-kernel sums are device time of a lane, not wall time
+        ext_s, shd_s = tot["kernel_ms"].get("wf_extend", 0.0) * 1e-3, tot["kernel_ms"].get("wf_shade", 0.0) * 1e-3
+        n_pairs = max(tot["kernels"].get("wf_shade", 0), 1)
+        roof["pipeline"] = {
+            "bytes_per_ray": EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY,
+            "achieved_gbs_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9, 3),
+            "frac_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+            "k_wf_extend": {"bytes_per_ray": EXTEND_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(ext_s * 1e3 / args.steps, 3),
+                            "achieved_gbs": round(EXTEND_BYTES_PER_RAY * rays / ext_s / 1e9, 3) if ext_s else None},
+            "k_wf_shade": {"bytes_per_ray": SHADE_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(shd_s * 1e3 / args.steps, 3),
+                           "mean_launch_ms": round(shd_s * 1e3 / n_pairs, 5),
+                           "achieved_gbs": round(SHADE_BYTES_PER_RAY * rays / shd_s / 1e9, 3) if shd_s else None,
+                           "frac": round(SHADE_BYTES_PER_RAY * rays / shd_s / 1e9 / HBM_PEAK_GBS, 6) if shd_s else None},
+            "stream_lanes": tot["lanes"], "launch_pairs_per_frame": n_pairs // args.steps,
+            "note": "the reference's shape: per sample and bounce one EXTEND + one SHADE launch, survivors compacted between bounces (wave ballot + mbcnt "
+                    "prefix, one atomic per 256-thread block); two interleaved sub-tiles on two HIP streams overlap one lane's launch tails with the other's traversal"}
+    elif name == "wavefront":
+        roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
+        roof["schedule"] = "one k_wf_generate + one k_wf_finish launch per frame (rt_schedule default: DESIGN.md §5)"
+    else:
+        roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache
+        roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
+    roof["note"] = ("a traversal kernel's algorithmic HBM traffic is its ray-state / frame stream only (SURVEY.md §8d); its real work is gathers from the "
+                    "cache-resident scene and instruction issue: see `binding` (measured VALU issue busy) and `traffic`")
+    return roof
+
+
+# ---- live counters ------------------------------------------------------------------------------------------------------------------
 def pmc_child(args):
-    """One untimed frame of the bench configuration (one renderer): the process `rocprofv3 --pmc ... --` wraps."""
+    """One untimed frame of the bench configuration per listed renderer: the process `rocprofv3 --pmc ... --` wraps."""
     from rtamd import abi, scenes
     from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
     sd = scenes.atrium_scene(args.detail)
     scene = Scene(sd, device=0, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
     cam = Camera.for_scene(sd, (args.width, args.height))
-    cls = WavefrontRenderer if args.renderer == "wavefront" else MegakernelRenderer
-    r = cls(scene, (args.width, args.height), args.depth, args.spp)
-    fr = r.render_frame(cam, want_f32=False, want_u8=False)
-    print(json.dumps({"rays": fr.rays, "device_ms": fr.device_ms}), flush=True)
-    r.close()
+    out = {}
+    for name in args.pmc_child.split(","):
+        cls = MegakernelRenderer if name == "megakernel" else WavefrontRenderer
+        r = cls(scene, (args.width, args.height), args.depth, args.spp)
+        if name == "wavefront_per_bounce":
+            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES)
+        fr = r.render_frame(cam, want_f32=False, want_u8=False)
+        out[name] = {"rays": fr.rays, "device_ms": fr.device_ms}
+        r.close()
+    print(json.dumps(out), flush=True)
     scene.close()
     return 0
 
 
+# one rocprofv3 pass per group (counters only, no trace domains)
 PMC_PASSES = (("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_MISS_sum"),
-              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"))
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE"),
+              ("SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_TRANS_F32"),
+              ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_SALU"))
+KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": ("k_wf_finish",), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade")}
 
 
-def live_pmc(args, renderer, kernel):
-    """Counters of `kernel` over ONE frame of this very configuration, each pass in its own child process under rocprofv3 --pmc
-    (counters only: no trace domains). Returns {counter: sum over the kernel's launches, "launches": n} or raises."""
+def live_pmc(args, renderers):
+    """Counters of the renderers' kernels over ONE frame each of this very configuration, every pass in its own child process under
+    rocprofv3 --pmc. Returns {kernel: {counter: sum over the kernel's launches, "launches": n}} or raises."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists():
         raise RuntimeError("rocprofv3 not found")
-    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", "--renderer", renderer, "--width", str(args.width), "--height", str(args.height),
+    child = [sys.executable, str(REPO / "bench.py"), "--pmc-child", ",".join(renderers), "--width", str(args.width), "--height", str(args.height),
              "--spp", str(args.spp), "--depth", str(args.depth), "--detail", str(args.detail), "--bvh", args.bvh]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_FORCE_DIST"):
         env.pop(k, None)
-    sums, launches = {}, 0
+    kernels = [k for r in renderers for k in KERNELS_OF[r]]
+    sums = {k: {"launches": 0} for k in kernels}
     for counters in PMC_PASSES:
         with tempfile.TemporaryDirectory(prefix="rt_pmc_", dir="/tmp") as d:
             p = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=120)
+                               capture_output=True, text=True, timeout=240)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if p.returncode != 0 or not files:
                 raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr[-300:]}")
-            ids = set()
+            ids = {k: set() for k in kernels}
             for f in files:
                 for row in csv.DictReader(open(f)):
-                    if kernel in row["Kernel_Name"]:
-                        sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                        ids.add(row["Dispatch_Id"])
-            launches = max(launches, len(ids))
-    sums["launches"] = launches
+                    for k in kernels:
+                        if k in row["Kernel_Name"]:
+                            sums[k][row["Counter_Name"]] = sums[k].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                            ids[k].add(row["Dispatch_Id"])
+            for k in kernels:
+                sums[k]["launches"] = max(sums[k]["launches"], len(ids[k]))
     return sums
 
 
-def attach_pmc(roof, best, args):
-    """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds)."""
-    kernel, name = roof["kernel"], best["renderer"]
-    # VALU issue ceiling of the kernel's DYNAMIC instruction mix: its three step kinds (inner node / whole leaf / shading round) priced
-    # opcode by opcode with the calibrated issue costs and weighted with the measured steps per ray (scripts/phase_cost.py ->
-    # profiles/r02_phase_cost.json; k_wf_finish and k_wf_extend run the same steps). The static whole-kernel mix of
-    # profiles/r02_valu_calibration.json over-weights the long, rarely executed shading code and is only the fallback.
-    ceiling, ceiling_source = None, None
-    phase_file, calib_file = REPO / "profiles" / "r02_phase_cost.json", REPO / "profiles" / "r02_valu_calibration.json"
-    if phase_file.exists():
-        ceiling = json.loads(phase_file.read_text()).get("per_ray", {}).get("dynamic_ceiling_cycles_per_instruction")
-        ceiling_source = "profiles/r02_phase_cost.json (dynamic mix: steps per ray x calibrated cost of each step kind)"
-    if ceiling is None and calib_file.exists():
-        ceil_key = "k_wf_extend_static_mix" if kernel == "k_wf_extend" else "k_megakernel_static_mix"
-        ceiling = json.loads(calib_file.read_text()).get("valu_ceiling_cycles_per_instruction", {}).get(ceil_key)
-        ceiling_source = "profiles/r02_valu_calibration.json (static whole-kernel mix)"
+def traffic_of(c, rays):
+    n = max(int(c.get("launches", 1)), 1)
+    fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0  # rocprofv3 reports both in KiB
+    hit, miss = c.get("TCC_HIT_sum"), c.get("TCC_MISS_sum")
+    return round((fetch + write) / n, 1), {
+        "fetch_bytes_per_launch": round(fetch / n, 1), "write_bytes_per_launch": round(write / n, 1),
+        "fetch_x2_upper_bound_per_launch": round((2 * fetch + write) / n, 1), "launches": n,
+        "bytes_per_ray": round((fetch + write) / max(rays, 1), 1), "l2_hit_rate": round(hit / (hit + miss), 4) if hit and miss else None}
+
+
+def binding_of(c, rays):
+    """The bound that binds, measured: VALU issue busy. SQ_ACTIVE_INST_VALU counts one unit per issued VALU instruction (two for the
+    8-cycle transcendentals), SQ_ACTIVE_INST_VALU2 the units that were issued as the SECOND instruction of a quad-cycle (gfx950 issues a
+    full-rate instruction — fma / mul / add / mov / and / or / xor / add_u32 / lshr — of one wave beside any instruction of another
+    wave); their difference is the number of quad-cycles in which the SIMD's vector ALU issued. Pinned on known instruction streams:
+    scripts/valu_calib2.hip, profiles/r03_valu_calibration2.json (0.94-0.99 on 100 %-VALU streams of every class and mix)."""
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+    n, a, a2 = c["SQ_INSTS_VALU"], c["SQ_ACTIVE_INST_VALU"], c["SQ_ACTIVE_INST_VALU2"]
+    busy = 4.0 * (a - a2) / (N_SIMDS * cycles)
+    b = {"bound": "valu_issue", "frac": round(busy, 4), "measured": "4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+         "kernel_cycles_per_valu_instruction": round(cycles * N_SIMDS / n, 3), "busy_cycles_per_valu_instruction": round(4.0 * (a - a2) / n, 3),
+         "dual_issued_share": round(2.0 * a2 / n, 4), "valu_instructions_per_ray": round(n / max(rays, 1), 1),
+         "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * a), 4) if c.get("SQ_THREAD_CYCLES_VALU") else None}
+    typed = {t: c.get("SQ_INSTS_VALU_" + t) for t in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")}
+    if all(v is not None for v in typed.values()):
+        b["instruction_mix"] = {t.lower(): round(v / n, 4) for t, v in typed.items()}
+        b["instruction_mix"]["other (cmp, cndmask, min/max, mov, logic, shifts)"] = round(1.0 - sum(typed.values()) / n, 4)
+        b["salu_per_valu"] = round(c.get("SQ_INSTS_SALU", 0.0) / n, 3)
+    b["note"] = ("frac = share of the kernel's cycles in which a SIMD's vector ALU issued an instruction (all SIMDs, whole launch, drain tail included): measured, "
+                 "no instruction-cost model. The rest is cycles with no VALU issue (waits on LDS / memory / scalar code in all resident waves).")
+    return b
+
+
+def attach_pmc(out, args):
+    """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds) of the headline
+    renderer and of the per-bounce pipeline, from counters collected in this run."""
+    lead = out["config"]["renderer"]
+    want = [lead] + (["wavefront_per_bounce"] if lead != "wavefront_per_bounce" and "wavefront_per_bounce" in out["renderers"] else [])
     c, source = None, None
     if not args.no_live_pmc:
         try:
-            c = live_pmc(args, name, kernel)
-            source = "measured in this run: one more frame of the same configuration in a child process under rocprofv3 --pmc (3 passes)"
+            c = live_pmc(args, want)
+            source = f"measured in this run: one more frame per renderer in a child process under rocprofv3 --pmc ({len(PMC_PASSES)} passes, counters only)"
         except Exception as e:  # no rocprofv3 / no counter access here: say so and use the committed profile of the same command
             source = f"live rocprofv3 --pmc unavailable ({str(e)[:160]}); "
     if c is None:
-        prof = REPO / "profiles" / "r02_pmc_bench.json"
+        prof = REPO / "profiles" / "r03_pmc_bench.json"
         if prof.exists():
-            c = json.loads(prof.read_text()).get(kernel)
-            source = (source or "") + "committed profiles/r02_pmc_bench.json (same command, scripts/final_profile.sh)"
-    if not c:
-        roof["traffic_note"] = (source or "") + "no counters available"
-        return
-    n = max(int(c.get("launches", 1)), 1)
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0  # rocprofv3 reports both in KiB
-        roof["traffic"] = round((fetch + write) / n, 1)
-        roof["traffic_detail"] = {"fetch_bytes_per_launch": round(fetch / n, 1), "write_bytes_per_launch": round(write / n, 1),
-                                  "fetch_x2_upper_bound_per_launch": round((2 * fetch + write) / n, 1),
-                                  "bytes_per_ray": round((fetch + write) / max(best["rays_per_frame"], 1), 1),
-                                  "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4) if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum") else None}
-        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of the kernel, separate --pmc passes, KiB -> bytes. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts a wide "
-                                "coalesced 16 B/lane stream at half its bytes; these reads are scattered 64-byte node / 48-byte triangle gathers (uncalibrated width), so the "
-                                "raw figure is `traffic` and the x2 bound is given beside it. Infinity-Cache hits are included (the scene is MALL-resident): this is fabric "
-                                "traffic, far above the algorithmic bytes because a traversal kernel's real work is gathers, not its output stream.")
-    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c and ceiling:
-        cycles = c["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
-        per_simd = c["SQ_INSTS_VALU"] / 1024.0       # 256 CUs x 4 SIMDs
-        achieved_cpi = cycles / max(per_simd, 1.0)   # kernel cycles per VALU instruction a SIMD issued
-        roof["binding"] = {"bound": "valu_issue", "frac": round(ceiling / achieved_cpi, 4),
-                           "achieved_cycles_per_valu_instruction": round(achieved_cpi, 3), "ceiling_cycles_per_valu_instruction": ceiling,
-                           "ceiling_source": ceiling_source,
-                           "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4) if c.get("SQ_ACTIVE_INST_VALU") else None,
-                           "valu_instructions_per_ray": round(c["SQ_INSTS_VALU"] / max(best["rays_per_frame"], 1), 1),
-                           "note": "frac = VALU issue cycles the kernel needs at the measured cost of its own instruction mix (profiles/r02_valu_calibration.json: a "
-                                   "wave64 VALU instruction costs 2, 4 or 8 cycles by opcode on gfx950) / kernel cycles. ~1 = the SIMDs issue VALU instructions "
-                                   "back to back: the kernel is bound by instruction issue at its lane utilisation, not by HBM, cache bandwidth or latency. The mix model is good to a "
-                                   "few percent (it prices every conditional push of an inner step), so a value slightly above 1 reads as 1; nothing is clamped."}
-    roof["pmc_source"] = source
+            c = json.loads(prof.read_text())
+            source = (source or "") + "committed profiles/r03_pmc_bench.json (same command: scripts/final_profile.sh)"
+    for name in want:
+        roof = out["renderers"][name]["roofline"]
+        rays = out["renderers"][name]["rays_per_frame"]
+        roof["pmc_source"] = source
+        if not c:
+            roof["traffic_note"] = "no counters available"
+            continue
+        main = c.get(roof["kernel"])
+        if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
+            roof["traffic"], roof["traffic_detail"] = traffic_of(main, rays)
+            roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of the kernel, separate --pmc passes, KiB -> bytes. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts a wide "
+                                    "coalesced 16 B/lane stream at half its bytes; scattered node / triangle gathers are of uncalibrated width, so the raw figure is "
+                                    "`traffic` and the x2 bound is given beside it. Infinity-Cache hits are included (the scene is MALL-resident): this is fabric traffic.")
+        if main and "SQ_ACTIVE_INST_VALU2" in main:
+            roof["binding"] = binding_of(main, rays)
+        if name == "wavefront_per_bounce" and c.get("k_wf_shade"):
+            sh = c["k_wf_shade"]
+            if "FETCH_SIZE" in sh:
+                t, detail = traffic_of(sh, rays)
+                roof["pipeline"]["k_wf_shade"]["traffic_per_launch"] = t
+                roof["pipeline"]["k_wf_shade"]["traffic_detail"] = detail
+                ms = roof["pipeline"]["k_wf_shade"].get("mean_launch_ms")
+                if ms:
+                    roof["pipeline"]["k_wf_shade"]["traffic_gbs"] = round(t / (ms * 1e-3) / 1e9, 1)
+            if "SQ_ACTIVE_INST_VALU2" in sh:
+                roof["pipeline"]["k_wf_shade"]["binding"] = binding_of(sh, rays)
+    out["roofline"] = out["renderers"][lead]["roofline"]
 
 
 def cpu_baseline(sd, W, H, depth, spp, renderer):
@@ -364,7 +507,7 @@ def cpu_baseline(sd, W, H, depth, spp, renderer):
     from rtamd import abi
     osc = O.OracleScene(sd)
     cam = O.camera(W, H, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
-    kind = abi.RT_RENDERER_WAVEFRONT if renderer == "wavefront" else abi.RT_RENDERER_MEGAKERNEL
+    kind = abi.RT_RENDERER_MEGAKERNEL if renderer == "megakernel" else abi.RT_RENDERER_WAVEFRONT
     cores = O.hardware_threads()
     t0 = time.perf_counter()
     _, _, rays = osc.render(cam, kind, depth, spp, use_bvh=True, nthreads=cores)

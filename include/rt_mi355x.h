@@ -262,6 +262,9 @@ typedef struct rt_stats {
     uint32_t samples_per_launch; /* samples of a pixel per k_wf_finish launch as resolved (spp = one launch per frame) */
     uint32_t finish_depth;       /* bounces rendered as EXTEND + SHADE launch pairs, min(schedule, max_depth)      */
     uint32_t cost_ordered;       /* 1 = the cost-ordered second launch ran                                          */
+    /* with profiling on (rt_renderer_set_profiling): summed hipEvent duration of the launches of the traversal / shading kernel
+     * families (RT_K_MEGAKERNEL, RT_K_WF_EXTEND, RT_K_WF_SHADE, RT_K_WF_FINISH), each on the stream it was launched on; else 0 */
+    double kernel_ms[RT_K_COUNT];
 } rt_stats;
 
 /* == IRenderer::render_frame(camera, scene) (src/render_megakernel.cpp:75-187,

@@ -176,6 +176,8 @@ struct rt_renderer {
         hipEvent_t ev_done = nullptr;
         std::vector<hipEvent_t> ev_pool;
         size_t n_hot = 0;
+        struct Span { uint32_t e0, e1; int kernel; }; // profiling: ev_pool[e0] .. ev_pool[e1] bracket one launch of `kernel`
+        std::vector<Span> spans;
     };
     std::vector<WfLane> lanes;
     hipEvent_t ev_fork = nullptr;
@@ -428,6 +430,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     for (uint32_t k = 0; k < K; ++k) {
         auto& L = r->lanes[k];
         L.n_hot = 0;
+        L.spans.clear();
         if (K > 1) HIPCHK(hipStreamWaitEvent(lane_stream(L), r->ev_fork, 0));
         if (L.n_local == 0) continue;
         grid[k] = (L.n_local + 255u) / 256u;
@@ -472,10 +475,10 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 hipStream_t ls = lane_stream(L);
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (r->profile_kernels && D0 == D) {
-                    e0 = pool_event(L.ev_pool, ne[k]), e1 = pool_event(L.ev_pool, ne[k] + 1);
-                    if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr; // profiling: e0 EXTEND e1 SHADE e2
+                if (r->profile_kernels) {
+                    e0 = pool_event(L.ev_pool, ne[k]), e1 = pool_event(L.ev_pool, ne[k] + 1), e2 = pool_event(L.ev_pool, ne[k] + 2);
+                    if (!e0 || !e1 || !e2) return fail(RT_ERR_HIP, "hipEventCreate failed");
                     HIPCHK(hipEventRecord(e0, ls));
                 }
                 if (r->d_stats)
@@ -484,10 +487,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 else
                     hipLaunchKernelGGL(k_wf_extend<false>, dim3(ext_grid[k]), dim3(RT_EXTEND_BLOCK), 0, ls, S, L.q[buf[k]], L.d_hits,
                                        counts + d, cursors + (size_t)s * D + d, (unsigned long long*)nullptr);
-                if (r->profile_kernels && D0 == D) {
-                    HIPCHK(hipEventRecord(e1, ls));
-                    ne[k] += 2;
-                }
+                if (r->profile_kernels) HIPCHK(hipEventRecord(e1, ls));
                 {
                     const int last = d + 1 == D ? 1 : 0, rr = r->rr_start && d + 1 >= r->rr_start && d + 1 < D ? 1 : 0;
 #define RT_SHADE_LAUNCH(RE, MS)                                                                                                         \
@@ -498,6 +498,12 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     else if (r->sched.matsort) RT_SHADE_LAUNCH(false, true);
                     else RT_SHADE_LAUNCH(false, false);
 #undef RT_SHADE_LAUNCH
+                }
+                if (r->profile_kernels) {
+                    HIPCHK(hipEventRecord(e2, ls));
+                    L.spans.push_back({(uint32_t)ne[k], (uint32_t)ne[k] + 1, RT_K_WF_EXTEND});
+                    L.spans.push_back({(uint32_t)ne[k] + 1, (uint32_t)ne[k] + 2, RT_K_WF_SHADE});
+                    ne[k] += 3;
                 }
                 launches.add(RT_K_WF_EXTEND), launches.add(RT_K_WF_SHADE);
                 if (r->sched.reorder) launches.also(RT_K_WF_SHADE_REORDER);
@@ -547,6 +553,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #undef RT_FINISH_LAUNCH
                 if (r->profile_kernels) {
                     HIPCHK(hipEventRecord(e1, ls));
+                    L.spans.push_back({(uint32_t)ne[k], (uint32_t)ne[k] + 1, RT_K_WF_FINISH});
                     ne[k] += 2;
                 }
                 launches.add(RT_K_WF_FINISH);
@@ -724,14 +731,17 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
             HIPCHK(hipEventElapsedTime(&k, r->ev_pool[i], r->ev_pool[i + 1]));
             local.hot_kernel_ms += k;
             local.hot_kernel_launches++;
+            local.kernel_ms[r->max_depth == 0 ? RT_K_FILL_BLACK : RT_K_MEGAKERNEL] += k;
         }
     } else {
+        // the dominant kernel of the schedule that ran: k_wf_extend where every bounce is a launch pair, k_wf_finish otherwise
+        const int hot = std::min(r->max_depth, r->sched.finish_depth) >= r->max_depth && r->max_depth > 0 ? RT_K_WF_EXTEND : RT_K_WF_FINISH;
         for (auto& L : r->lanes)
-            for (size_t i = 0; i + 1 < L.n_hot; i += 2) {
+            for (const auto& sp : L.spans) {
                 float k = 0.0f;
-                HIPCHK(hipEventElapsedTime(&k, L.ev_pool[i], L.ev_pool[i + 1]));
-                local.hot_kernel_ms += k;
-                local.hot_kernel_launches++;
+                HIPCHK(hipEventElapsedTime(&k, L.ev_pool[sp.e0], L.ev_pool[sp.e1]));
+                local.kernel_ms[sp.kernel] += k;
+                if (sp.kernel == hot) local.hot_kernel_ms += k, local.hot_kernel_launches++;
             }
     }
     if (r->n_local) {

@@ -121,6 +121,7 @@ class rt_stats(C.Structure):
         ("samples_per_launch", C.c_uint32),
         ("finish_depth", C.c_uint32),
         ("cost_ordered", C.c_uint32),
+        ("kernel_ms", C.c_double * RT_K_COUNT),
     ]
 
 

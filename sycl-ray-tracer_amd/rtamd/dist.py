@@ -22,7 +22,7 @@ def max_local_rows(world: int, height: int, strip_rows: int = 8) -> int:
 
 class FrameGatherer:
     """Pre-allocates everything the per-frame exchange needs, so the timed region only launches the
-    collective and the de-interleave copies."""
+    collective and ONE de-interleave gather."""
 
     def __init__(self, rank: int, world: int, width: int, height: int, strip_rows: int, device: torch.device,
                  channels: int = 4, dtype=torch.float32, collective: bool | None = None):
@@ -32,22 +32,27 @@ class FrameGatherer:
         pad_rows = max_local_rows(world, height, strip_rows)
         # every rank contributes the same (padded) shape: torch.distributed.gather needs equal sizes
         self.local = torch.zeros((pad_rows, width, channels), dtype=dtype, device=device)
-        self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
-        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and self.collective) else None
-        self.index = None
+        self.frame = self.gathered = self.parts = self.src_row = None
         if rank == 0:
-            self.index = [torch.tensor(strip_rows_of(r, world, height, strip_rows), dtype=torch.long, device=device)
-                          for r in range(world)]
+            self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device)
+            # the ranks' padded tiles land back to back in ONE buffer (the gather list is its slices: no copies) ...
+            self.gathered = torch.zeros((world * pad_rows, width, channels), dtype=dtype, device=device)
+            self.parts = [self.gathered[r * pad_rows:(r + 1) * pad_rows] for r in range(world)]
+            # ... and one index_select over rows (global row y <- row src_row[y] of the buffer) de-interleaves the whole frame
+            src = torch.empty(height, dtype=torch.long)
+            for r in range(world):
+                rows = strip_rows_of(r, world, height, strip_rows)
+                src[rows] = r * pad_rows + torch.arange(len(rows))
+            self.src_row = src.to(device)
 
     def gather(self):
         """Collects `self.local` of every rank into `self.frame` on rank 0. Returns the frame (rank 0) or None."""
         if self.collective:
             dist.gather(self.local, self.parts, dst=0)
-            if self.rank == 0:
-                for r in range(self.world):
-                    self.frame.index_copy_(0, self.index[r], self.parts[r][: self.index[r].numel()])
-        else:
-            self.frame.index_copy_(0, self.index[0], self.local[: self.rows])
+        elif self.rank == 0:
+            self.parts[0].copy_(self.local)
+        if self.rank == 0:
+            torch.index_select(self.gathered, 0, self.src_row, out=self.frame)
         # The renderer writes `self.local` from its own HIP stream: the next frame must not start before this
         # exchange has read it (and rank 0's frame is complete when gather() returns).
         if self.local.is_cuda:

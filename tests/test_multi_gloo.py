@@ -62,3 +62,51 @@ def test_strip_ownership_partitions_the_frame():
             assert max(len(r) for r in rows) == max_local_rows(world, h, 8)
     # 1080p over 8 GPUs: 135 strips -> 17 or 16 strips per rank
     assert sorted({len(strip_rows_of(r, 8, 1080)) for r in range(8)}) == [128, 136]
+
+
+def _bench(args, env_extra=None, timeout=240):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(REPO / "bench.py")] + [str(a) for a in args], cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(tmp_path, oracle, world):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE): it must start its N ranks itself (a torch.distributed.run
+    child process), run the multi-rank path — process group, all-reduces, gather, de-interleave — and print the one JSON line with the
+    per-rank fields. Rehearsed on the CPU: backend gloo, the ranks' tiles rendered beforehand by the oracle and read from files
+    (bench.py itself has no CPU renderer); the frame rank 0 assembled must be the oracle's full frame."""
+    import json
+    from rtamd import scenes
+    w, h, strip = 64, 45, 8
+    sd = scenes.cornell_scene()
+    sc = oracle.OracleScene(sd)
+    cam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    for rank in range(world):
+        f, _, _ = sc.render(cam, 1, 4, 2, rank=rank, world=world, strip_rows=strip)
+        np.save(tmp_path / f"tile_{rank}.npy", f)
+    full, _, _ = sc.render(cam, 1, 4, 2)
+    out = tmp_path / "frame.npy"
+    p = _bench(["--gpus", world, "--steps", 3, "--warmup", 1, "--width", w, "--height", h, "--backend", "gloo", "--rehearsal-tiles", tmp_path, "--dump-frame", out])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and d["steps"] == 3 and d["warmup"] == 1
+    assert len(d["per_rank_ms"]) == world and all(ms > 0 for ms in d["per_rank_ms"]) and d["gather_ms"] > 0
+    assert d["scaling"] == "strong" and d["ms_per_step"] > 0
+    np.testing.assert_array_equal(np.load(out), full)
+
+
+def test_bench_launcher_reports_a_failing_rank(tmp_path):
+    """A rank that fails (here: its tile file is missing) must make `bench.py --gpus N` exit non-zero, not hang and not print a line."""
+    np.save(tmp_path / "tile_0.npy", np.zeros((24, 16, 4), np.float32))  # tile_1.npy is missing
+    p = _bench(["--gpus", 2, "--steps", 1, "--warmup", 0, "--width", 16, "--height", 40, "--backend", "gloo", "--rehearsal-tiles", tmp_path], timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+def test_bench_refuses_a_cpu_backend_without_tiles():
+    p = _bench(["--gpus", 1, "--backend", "gloo"])
+    assert p.returncode != 0 and "rehearsal" in (p.stdout + p.stderr)
