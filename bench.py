@@ -11,12 +11,13 @@ before the timed region; the frame stays on the device (no PCIe traffic inside t
 GPU (this process never imports torch) it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py` as
 a child process, relays its JSON line and exits with its code. Under an external launcher (WORLD_SIZE set) it is one rank.
 
-Three renderers of the path are measured with the same K steps:
-  wavefront             the WavefrontRenderer's default schedule: one k_wf_generate + one k_wf_finish launch per frame
-  megakernel            the MegakernelRenderer
-  wavefront_per_bounce  the WavefrontRenderer in the reference's shape (src/render_wavefront.cpp:396-417): per sample and bounce one
-                        k_wf_extend + one k_wf_shade launch, survivors compacted between bounces with __ballot / mbcnt ranks
-The headline `value` is the fastest (`config.renderer`); `renderers` holds all three with their rooflines.
+Four renderers of the path are measured with the same K steps:
+  wavefront                   the WavefrontRenderer's default schedule: one k_wf_generate + one k_wf_finish launch per frame
+  megakernel                  the MegakernelRenderer
+  wavefront_per_bounce        the WavefrontRenderer in the reference's shape (src/render_wavefront.cpp:396-417), a launch per sample and
+                              bounce with the survivors compacted between bounces (__ballot / mbcnt ranks): k_wf_extend + k_wf_shade
+  wavefront_per_bounce_fused  the same with ONE kernel per bounce (intersect + shade + compact: the reference's shoot_rays, :222-312)
+The headline `value` is the fastest (`config.renderer`); `renderers` holds all four with their rooflines.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak (the
@@ -58,8 +59,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 # 76 B/ray (34 B state read + 8 B RNG r/w + 34 B state write). In the per-bounce schedule that kernel is split in two:
 #   k_wf_extend (dominant in time): reads org+id 16 B + dir 8 B, writes the hit record 16 B                          = 40 B/ray
 #   k_wf_shade                    : reads state 34 B + hit 16 B + RNG 4 B, writes RNG 4 B + state 34 B                = 92 B/ray
+# and the fused per-bounce kernel (k_wf_finish limited to one bounce, "SHOOT") moves exactly SURVEY's 76 B/ray.
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
+SHOOT_BYTES_PER_RAY = 76
 # The wavefront renderer's default schedule: one queue per frame, written by k_wf_generate (34 B state + 4 B RNG r/w)
 # and consumed by k_wf_finish, which follows every path to its end in registers:
 #   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
@@ -69,7 +72,7 @@ MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel pe
 # per-ray counts of the atrium measured with RT_KERNEL_STATS=1: 17.10 nodes, 4.60 triangles
 TRAVERSAL_BYTES_PER_RAY = 17.10 * 64 + 4.60 * 48 + 124
 N_SIMDS = 1024                   # 256 CUs x 4
-RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce")
+RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce", "wavefront_per_bounce_fused")
 
 
 def parse_args(argv=None):
@@ -186,8 +189,8 @@ def main() -> int:
     def make_renderer(name):
         cls = MegakernelRenderer if name == "megakernel" else WavefrontRenderer
         r = cls(scene, (W, H), args.depth, args.spp)
-        if name == "wavefront_per_bounce":
-            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES)
+        if name.startswith("wavefront_per_bounce"):
+            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES, fused_bounce=name.endswith("fused"))
         r.set_tile(rank, world, strip)
         r.set_profiling(True)  # per-launch hipEvents of the traversal / shading kernels, on the launches' own streams
         return r
@@ -319,9 +322,11 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed):
     hot_launches, hot_ms = tot["hot_launches"], tot["hot_ms"]
     rays = tot["rays"]
     if name == "wavefront":
-        kernel, bytes_per_launch = "k_wf_finish", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
+        kernel, bytes_per_launch = "k_wf_finish<false, false, false>", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
     elif name == "wavefront_per_bounce":
         kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
+    elif name == "wavefront_per_bounce_fused":
+        kernel, bytes_per_launch = "k_wf_finish<false, false, true>", SHOOT_BYTES_PER_RAY * rays / max(hot_launches, 1)
     else:
         kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
     mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
@@ -347,6 +352,11 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed):
             "stream_lanes": tot["lanes"], "launch_pairs_per_frame": n_pairs // args.steps,
             "note": "the reference's shape: per sample and bounce one EXTEND + one SHADE launch, survivors compacted between bounces (wave ballot + mbcnt "
                     "prefix, one atomic per 256-thread block); two interleaved sub-tiles on two HIP streams overlap one lane's launch tails with the other's traversal"}
+    elif name == "wavefront_per_bounce_fused":
+        roof["bytes_per_ray"] = SHOOT_BYTES_PER_RAY
+        roof["stream_lanes"] = tot["lanes"]
+        roof["schedule"] = ("one launch per sample and bounce of k_wf_finish limited to one bounce (SHOOT): intersect, shade, survivors compacted into the next queue — wave "
+                            "ballot + mbcnt ranks, slots from a per-workgroup block (one device atomic per 256 rays)")
     elif name == "wavefront":
         roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
         roof["schedule"] = "one k_wf_generate + one k_wf_finish launch per frame (rt_schedule default: DESIGN.md §5)"
@@ -370,8 +380,8 @@ def pmc_child(args):
     for name in args.pmc_child.split(","):
         cls = MegakernelRenderer if name == "megakernel" else WavefrontRenderer
         r = cls(scene, (args.width, args.height), args.depth, args.spp)
-        if name == "wavefront_per_bounce":
-            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES)
+        if name.startswith("wavefront_per_bounce"):
+            r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES, fused_bounce=name.endswith("fused"))
         fr = r.render_frame(cam, want_f32=False, want_u8=False)
         out[name] = {"rays": fr.rays, "device_ms": fr.device_ms}
         r.close()
@@ -385,7 +395,8 @@ PMC_PASSES = (("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_MISS_sum"),
               ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE"),
               ("SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_TRANS_F32"),
               ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_SALU"))
-KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": ("k_wf_finish",), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade")}
+KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": ("k_wf_finish<false, false, false>",), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade"),
+              "wavefront_per_bounce_fused": ("k_wf_finish<false, false, true>",)}
 
 
 def live_pmc(args, renderers):
@@ -457,7 +468,7 @@ def attach_pmc(out, args):
     """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds) of the headline
     renderer and of the per-bounce pipeline, from counters collected in this run."""
     lead = out["config"]["renderer"]
-    want = [lead] + (["wavefront_per_bounce"] if lead != "wavefront_per_bounce" and "wavefront_per_bounce" in out["renderers"] else [])
+    want = [lead] + [n for n in ("wavefront_per_bounce", "wavefront_per_bounce_fused") if n != lead and n in out["renderers"]]
     c, source = None, None
     if not args.no_live_pmc:
         try:

@@ -213,6 +213,10 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
  *                       blocks first. -1 = automatic (>= 32 spp, 1..4 pixel generations), 0 = off, 1 = whenever the tile
  *                       consists of whole 8x8 blocks (a tile that does not falls back to queue order).
  *   hip_graph           1 = the frame's launches are captured once and replayed as a hipGraph.
+ *   fused_bounce        1 = the bounces rendered launch by launch (finish_depth) use ONE kernel per bounce that intersects, shades and
+ *                       compacts the survivors into the next queue — shoot_rays as the reference has it (src/render_wavefront.cpp:222-312)
+ *                       — instead of the EXTEND + SHADE pair with its hit-record round trip. reorder / matsort act in k_wf_shade and
+ *                       are ignored then.
  * The environment variables RT_WF_FINISH_DEPTH / _SAMPLES_PER_LAUNCH / _STREAMS / _REQUEUE / _REORDER / _MATSORT / _LPT /
  * _GRAPH still work: rt_renderer_create turns them into the initial rt_schedule (a shim for scripts; tests use the API). */
 #define RT_SCHED_ALL_BOUNCES 0xFFFFFFFFu
@@ -225,6 +229,7 @@ typedef struct rt_schedule {
     uint32_t matsort;
     int32_t cost_order;
     uint32_t hip_graph;
+    uint32_t fused_bounce;
 } rt_schedule;
 /* Megakernel renderers accept the call and ignore every field. No frame may be in flight; the tile's queues are re-allocated. */
 int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s);
@@ -246,6 +251,7 @@ enum {
     RT_K_WF_TILE_ORDER = 9, /* k_wf_tile_cost + k_wf_order_tiles (cost ordering) */
     RT_K_WF_RESOLVE = 10,
     RT_K_FILL_BLACK = 11,
+    RT_K_WF_SHOOT = 12, /* k_wf_finish limited to one bounce: intersect + shade + compact, one launch per bounce (fused_bounce) */
     RT_K_COUNT = 16
 };
 

@@ -10,7 +10,7 @@ for v in "$@"; do
   python3 scripts/quick_bench.py $spp $R 2>&1 | grep -v "^\[rt stats\] waves\|timeline"
   D=gpurun_out/r03/ab/$v
   rm -rf $D; mkdir -p $D
-  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE --output-format csv -d $D -- python3 bench.py --pmc-child --renderer $( [ "$R" = mega ] && echo megakernel || echo wavefront ) --spp $spp > $D.out 2> $D.err
+  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE --output-format csv -d $D -- python3 bench.py --pmc-child $( [ "$R" = mega ] && echo megakernel || echo wavefront ) --spp $spp > $D.out 2> $D.err
   python3 - <<PY
 import csv, glob, collections
 s = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -11,7 +11,7 @@ for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE
          "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_INSTS_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
          "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/p$i -- python3 bench.py --pmc-child --renderer $R --spp $SPP "$@" > $O/p$i.out 2> $O/p$i.err || { echo "pass $i failed"; tail -3 $O/p$i.err; }
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/p$i -- python3 bench.py --pmc-child $R --spp $SPP "$@" > $O/p$i.out 2> $O/p$i.err || { echo "pass $i failed"; tail -3 $O/p$i.err; }
 done
 python3 - <<PY
 import csv, glob, collections

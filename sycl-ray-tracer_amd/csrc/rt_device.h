@@ -173,6 +173,9 @@ struct Trav {
     float ox, oy, oz;     // -o/d
     Hit best;
     int32_t cur;
+#if RT_WIDE_NODES
+    uint32_t nx, ny, nz; // byte offsets of the ray's NEAR plane words inside a WideNode (x: 0 / 16, y: 32 / 48, z: 64 / 80); far = near ^ 16
+#endif
     uint32_t sp; // LDS byte address of the lane's next free stack entry (TravStack::base = empty); beyond the LDS part it keeps counting
 #if RT_POSTPONE
     int32_t pend = kTravDone; // a postponed leaf (same code as `cur`) or kTravDone: none. Invariant: cur == kTravDone => pend == kTravDone
@@ -195,6 +198,9 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
     const float dz = __builtin_fabsf(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z;
     T.ix = __builtin_amdgcn_rcpf(dx), T.iy = __builtin_amdgcn_rcpf(dy), T.iz = __builtin_amdgcn_rcpf(dz);
     T.ox = -o.x * T.ix, T.oy = -o.y * T.iy, T.oz = -o.z * T.iz;
+#if RT_WIDE_NODES
+    T.nx = T.ix < 0.0f ? 16u : 0u, T.ny = T.iy < 0.0f ? 48u : 32u, T.nz = T.iz < 0.0f ? 80u : 64u;
+#endif
     T.cur = 0; // root
     T.sp = stack_base(st); // empty stack
 #if RT_POSTPONE
@@ -257,12 +263,26 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
 // visits of an average ray fall into these nodes; taking them out of the vector L1 path (the first
 // versions were bound by L1 tag throughput: ~1 lane-load per cycle and CU) is worth more than any ALU saving.
 #ifndef RT_TOP_NODES
+#if RT_WIDE_NODES
+#define RT_TOP_NODES 170 // 128-byte nodes: the same 21.8 KB of LDS
+#else
 #define RT_TOP_NODES 341
+#endif
 #endif
 constexpr int kTopNodes = RT_TOP_NODES;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+#if RT_WIDE_NODES
+struct TopTree {
+    uint32_t base; // LDS byte address of node 0's record (128 bytes per node, as in memory)
+    int32_t bytes; // nodes staged x 128 (0 = none): a node reference (byte offset) below this is read from LDS
+};
+RT_DEV void top_tree_fill(const SceneDev& S, u32x4* rec, int32_t count) {
+    const u32x4* np = reinterpret_cast<const u32x4*>(S.wnodes);
+    for (int32_t i = (int32_t)threadIdx.x; i < count * 8; i += (int32_t)blockDim.x) rec[i] = np[i];
+}
+#else
 struct TopTree {
     lds_u32x4* w0; // origin.xyz, scale.x
     lds_u32x4* w1; // qlo_x, qhi_x, qlo_y, qhi_y
@@ -280,6 +300,7 @@ RT_DEV void top_tree_fill(const SceneDev& S, u32x4* w0, u32x4* w1, u32x4* w2, u3
         ch[i] = np[3];
     }
 }
+#endif
 
 // ---- instruction selection helpers (profiles/r02_valu_calibration.json) ------------------------------------------------
 // The traversal kernels are bound by VALU issue cycles, and on gfx950 a select is cheap or dear by its ENCODING: v_cndmask_b32_e64
@@ -325,11 +346,47 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 #ifndef RT_LEAF_UNROLL
 #define RT_LEAF_UNROLL 0
 #endif
+#ifndef RT_INTERLEAVE
+#define RT_INTERLEAVE 0
+#endif
 #ifndef RT_SORT_CE
 #define RT_SORT_CE 4 // 5: full sorting network. 4 (default): nearest and farthest exact, the middle two in either order (-18 issue cycles per
                      // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3: only the nearest exact (+-0)
 #endif
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top) {
+    const float inf = __builtin_huge_valf();
+    float k0, k1, k2, k3;
+#if RT_WIDE_NODES
+    // fp32 planes, near / far words picked by address: no conversions, no selects; t = plane * inv - o * inv in one fma per plane
+    u32x4 pnx, pfx, pny, pfy, pnz, pfz, chw;
+    if (T.cur < top.bytes) { // top of the tree: LDS
+        const uint32_t a = top.base + (uint32_t)T.cur;
+        pnx = *(lds_u32x4*)(size_t)(a + T.nx), pfx = *(lds_u32x4*)(size_t)(a + (T.nx ^ 16u));
+        pny = *(lds_u32x4*)(size_t)(a + T.ny), pfy = *(lds_u32x4*)(size_t)(a + (T.ny ^ 16u));
+        pnz = *(lds_u32x4*)(size_t)(a + T.nz), pfz = *(lds_u32x4*)(size_t)(a + (T.nz ^ 16u));
+        chw = *(lds_u32x4*)(size_t)(a + 96u);
+    } else {
+        const char* np = reinterpret_cast<const char*>(S.wnodes) + (uint32_t)T.cur;
+        pnx = *reinterpret_cast<const u32x4*>(np + T.nx), pfx = *reinterpret_cast<const u32x4*>(np + (T.nx ^ 16u));
+        pny = *reinterpret_cast<const u32x4*>(np + T.ny), pfy = *reinterpret_cast<const u32x4*>(np + (T.ny ^ 16u));
+        pnz = *reinterpret_cast<const u32x4*>(np + T.nz), pfz = *reinterpret_cast<const u32x4*>(np + (T.nz ^ 16u));
+        chw = *reinterpret_cast<const u32x4*>(np + 96);
+    }
+    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
+#define RT_CHILD(K, C)                                                                                                                     \
+    {                                                                                                                                     \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(__uint_as_float(pnx.C), T.ix, T.ox), __builtin_fmaf(__uint_as_float(pny.C), T.iy, T.oy)), \
+                                         __builtin_fmaxf(__builtin_fmaf(__uint_as_float(pnz.C), T.iz, T.oz), 0.0f));                      \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(__uint_as_float(pfx.C), T.ix, T.ox), __builtin_fmaf(__uint_as_float(pfy.C), T.iy, T.oy)), \
+                                         __builtin_fminf(__builtin_fmaf(__uint_as_float(pfz.C), T.iz, T.oz), T.best.t));                  \
+        K = sel(lanes(tn <= tf), inf, tn);                                                                                                \
+    }
+    RT_CHILD(k0, x)
+    RT_CHILD(k1, y)
+    RT_CHILD(k2, z)
+    RT_CHILD(k3, w)
+#undef RT_CHILD
+#else
     u32x4 w0, w1, w2, chw;
     if (T.cur < top.count) { // top of the tree: LDS
         w0 = top.w0[T.cur], w1 = top.w1[T.cur], w2 = top.w2[T.cur], chw = top.ch[T.cur];
@@ -358,7 +415,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     const uint32_t qny = sel(ny, w1.z, w1.w), qfy = sel(ny, w1.w, w1.z);
     const uint32_t qnz = sel(nz, w2.x, w2.y), qfz = sel(nz, w2.y, w2.x);
 #endif
-    const float inf = __builtin_huge_valf();
     // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
     // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 costs
     // 4 cycles per pair, the same as two v_fma_f32.)
@@ -368,7 +424,21 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     // for any child, absent or not — so the child words are not tested here (an explicit kChildEmpty test per slot was measured at
     // 12 issue cycles of ~500 per step).
     int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
-    float k0, k1, k2, k3;
+#if RT_INTERLEAVE // experiment: every conversion directly followed by its fma (pinned with scheduling fences)
+#define RT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define RT_CHILD(K, CVT)                                                                                  \
+    {                                                                                                    \
+        const float t0 = __builtin_fmaf(CVT(qnx), ax, bx); RT_FENCE                                       \
+        const float t1 = __builtin_fmaf(CVT(qny), ay, by); RT_FENCE                                       \
+        const float t2 = __builtin_fmaf(CVT(qnz), az, bz); RT_FENCE                                       \
+        const float t3 = __builtin_fmaf(CVT(qfx), ax, bx); RT_FENCE                                       \
+        const float t4 = __builtin_fmaf(CVT(qfy), ay, by); RT_FENCE                                       \
+        const float t5 = __builtin_fmaf(CVT(qfz), az, bz); RT_FENCE                                       \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, 0.0f));            \
+        const float tf = __builtin_fminf(__builtin_fminf(t3, t4), __builtin_fminf(t5, T.best.t));        \
+        K = sel(lanes(tn <= tf), inf, tn);                                                               \
+    }
+#else
 #define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
@@ -377,11 +447,13 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
         K = sel(lanes(tn <= tf), inf, tn);                                                               \
     }
+#endif
     RT_CHILD(k0, ub0)
     RT_CHILD(k1, ub1)
     RT_CHILD(k2, ub2)
     RT_CHILD(k3, ub3)
 #undef RT_CHILD
+#endif // RT_WIDE_NODES
     // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
     // SGPR pair + four e64 selects on it (18 cycles).
 #define RT_CE(KA, CA, KB, CB)                                                        \
@@ -542,7 +614,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #if RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
 #else
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes));
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * (RT_WIDE_NODES ? 128 : 1)));
 #endif
         if (inner) trav_inner(S, T, stack, top);
     } else {

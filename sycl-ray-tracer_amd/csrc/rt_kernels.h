@@ -45,6 +45,17 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
 }
 
 // LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
+#if RT_WIDE_NODES
+#define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
+    __shared__ u32x4 top_rec[kTopNodes * 8];                                                           \
+    __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
+    int32_t spill[kStackSize - kLdsStack];                                                             \
+    const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
+    top_tree_fill(S, top_rec, top_count);                                                              \
+    __syncthreads();                                                                                   \
+    const TopTree top{(uint32_t)(size_t)(lds_u32x4*)top_rec, top_count * 128};                         \
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
+#else
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
     __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_w2[kTopNodes], top_ch[kTopNodes];       \
     __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
@@ -54,6 +65,7 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     __syncthreads();                                                                                   \
     const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
     const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
+#endif
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
@@ -773,6 +785,8 @@ struct FinishRequeue {
     uint32_t capacity;           // >= P (host-sized)
 };
 constexpr uint32_t kRqIdleCap = 1u << 26;
+constexpr uint32_t kOutBlock = 256u;   // SHOOT: slots of the next queue a workgroup reserves per device atomic
+constexpr uint32_t kNoRay = 0xFFFFFFFFu; // pixel id of a hole in a SHOOT-produced queue
 #ifndef RT_RQ_STAGE
 #define RT_RQ_STAGE 96u
 #endif
@@ -793,13 +807,34 @@ static_assert(kRqFlush + 64u <= kRqStage, "a whole wave of new entries must fit 
 RT_DEV unsigned long long rq_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RT_DEV void rq_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <bool STATS, bool REQ>
+// LIMIT (k_wf_finish<.., false, true>, "SHOOT": rt_schedule::fused_bounce): the lane follows its ray for `bounce_limit` bounces only and
+// then hands it on — survivors are COMPACTED into the next queue `qout` (__ballot + mbcnt ranks inside the wave, one atomic per wave
+// and shading round) with the pixel's RNG word stored back, exactly what the reference's shoot_rays does per bounce
+// (src/render_wavefront.cpp:244-312: intersect, shade, compact, one kernel). With bounce_limit = 1 this is the reference's schedule as
+// ONE launch per bounce: no hit-record round trip (EXTEND -> SHADE costs 32 B per ray) and half the launches of the split pipeline.
+template <bool STATS, bool REQ, bool LIMIT = false>
 __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
                                                                     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
                                                                     unsigned long long* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
                                                                     uint32_t n_samples, uint32_t rr_start,
-                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots, uint8_t* __restrict__ cost_out) {
+                                                                    unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots, uint8_t* __restrict__ cost_out,
+                                                                    QueueDev qout = QueueDev{}, uint32_t* __restrict__ count_out = nullptr, uint32_t bounce_limit = 0,
+                                                                    uint32_t qflags = 0) {
+    static_assert(!(REQ && LIMIT), "the dynamic queue and the per-bounce hand-over are different schedules");
+    // qflags & 1 (every launch of a frame whose bounces are SHOOT launches): the input queue may hold HOLES (entries whose pixel id is
+    // kNoRay: the unused tail of a workgroup's last output block, below) and is therefore longer than the number of rays in it, so every
+    // traced ray is counted here, on the device, instead of by the host as a queue length.
+    const bool holes = (qflags & 1u) != 0u;
+    // SHOOT's compaction. One device-scope atomic on the next queue's length per wave and shading round was measured at ~6 ns each,
+    // serialised (46 k per launch of 2 M rays: 270 of 600 us). So output slots are handed out in two levels: a workgroup owns a BLOCK of
+    // kOutBlock slots of the next queue (one device atomic per block), and its eight independent waves take their slots from the block
+    // with one LDS atomic on a 64-bit word {block base : slots used}. The wave whose request crosses the block's end fills the old block,
+    // fetches the next one and publishes it; waves that arrive in between wait for the new word (the owner depends on nobody). What a
+    // workgroup leaves unused in its last block when its last wave exits is marked kNoRay: <= kOutBlock - 1 holes per workgroup and launch.
+    __shared__ unsigned long long out_word;
+    __shared__ uint32_t out_exited;
+    if (LIMIT && threadIdx.x == 0) out_word = (unsigned long long)kOutBlock, out_exited = 0u; // "no block yet": used == kOutBlock (before the LDS barrier below)
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
@@ -831,8 +866,21 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     uint32_t chunk_pos = wave_id * chunk_slots; // first chunk static, later ones from the cursor (as EXTEND)
     uint32_t chunk_end = chunk_pos + chunk_slots < n ? chunk_pos + chunk_slots : n;
     bool exhausted = chunk_pos >= n; // the sample-0 queue has no chunk left for this wave
+    auto leave = [&]() { // SHOOT: the workgroup's last wave to exit marks the unused tail of the workgroup's output block
+        if (!LIMIT) return;
+        uint32_t order = 0;
+        if (lane == 0) order = atomicAdd(&out_exited, 1u);
+        order = (uint32_t)__builtin_amdgcn_readfirstlane((int)order);
+        if (order + 1u != kWavesPerBlock) return;
+        const unsigned long long w = out_word; // every other wave of the workgroup has left: the word is final
+        const uint32_t used = (uint32_t)w, base = (uint32_t)(w >> 32);
+        for (uint32_t i = used + lane; i < kOutBlock; i += 64u) qout.org_id[base + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNoRay));
+    };
     if (exhausted) {
-        if (!REQ) return;
+        if (!REQ) {
+            leave();
+            return;
+        }
         chunk_pos = chunk_end = 0;
     }
     auto flush = [&]() { // REQ: append the wave's staged entries to the dynamic queue
@@ -865,6 +913,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                         // A slot is a whole pixel-chain when the lane keeps its pixel for several samples: then a wave takes exactly as
                         // many slots as it has idle lanes (as k_megakernel does), never a private chunk that it would still be working
                         // through when the other waves have left. Single paths are short: there a chunk per atomic is right.
+                        // (SHOOT with guided chunk sizes — a share of what is left, 512 ... 64 slots, to save cursor atomics — was measured slower:
+                        // 58.6 -> 66.2 ms at 16 spp; a wave that starts a long private chunk near the end sets the launch's tail.)
                         const uint32_t w = !REQ && n_samples > 1u ? cnt : chunk_slots;
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(cursor, w);
@@ -900,11 +950,13 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                             waiting = true;
                         } else {
                             id = queue_load(qin, chunk_pos + rank, r);
-                            rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
-                            depth = first_depth;
-                            samples_left = n_samples, first_counted = true;
-                            trav_begin(T, r.org, ray_dir(r), stack);
-                            live = true;
+                            if (!(holes && id == kNoRay)) { // (a hole: the slot is consumed, the lane stays idle until the next refill)
+                                rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
+                                depth = first_depth;
+                                samples_left = n_samples, first_counted = !holes;
+                                trav_begin(T, r.org, ray_dir(r), stack);
+                                live = true;
+                            }
                         }
                     }
                     chunk_pos += take;
@@ -948,9 +1000,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
 #if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        bool requeue = false, slot_finished = false;
+        bool requeue = false, slot_finished = false, hand_on = false;
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
-            if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum
+            if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes)
             f3 res;
             const bool done = shade_bounce(S, rng, r, T.best, res);
             depth++;
@@ -988,8 +1040,42 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                 live = false, slot_finished = true;
                 if (REQ) requeue = samples_left > 1u;
                 if (!requeue) rng_buf[id] = rng; // ScopedRng store (the next launch reads it; inside this launch the word travels in the entry)
+            } else if (LIMIT && depth - first_depth >= bounce_limit) {
+                hand_on = true, live = false, slot_finished = true; // the survivor goes to the next bounce's queue (below)
             } else {
                 trav_begin(T, r.org, ray_dir(r), stack);
+            }
+        }
+        if (LIMIT) { // compaction of the survivors into the next queue: src/render_wavefront.cpp:282-311 (there: per 16-item work-group through LDS)
+            const unsigned long long hm = __ballot(hand_on);
+            if (hm != 0ull) {
+                const uint32_t n_req = (uint32_t)__popcll(hm);
+                uint32_t b0 = 0, c0 = 0, b1 = 0; // slots [b0, b0 + c0) of the current block, the rest from b1 on (a new block)
+                if (lane == 0) {
+                    for (;;) {
+                        const unsigned long long old = atomicAdd(&out_word, (unsigned long long)n_req); // LDS
+                        const uint32_t used = (uint32_t)old, base = (uint32_t)(old >> 32);
+                        if (used + n_req <= kOutBlock) { // fits
+                            b0 = base + used, c0 = n_req;
+                            break;
+                        }
+                        if (used <= kOutBlock) { // this request crosses the block's end: fill it, fetch the next block, publish it
+                            b0 = base + used, c0 = kOutBlock - used;
+                            b1 = atomicAdd(count_out, kOutBlock); // the one device-scope atomic per kOutBlock rays
+                            __hip_atomic_store(&out_word, ((unsigned long long)b1 << 32) | (unsigned long long)(n_req - c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            break;
+                        }
+                        // the block is used up and its last taker is fetching the next one: wait for the new word, then ask again
+                        while ((uint32_t)__hip_atomic_load(&out_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > kOutBlock) __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0), c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+                b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b1);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if (hand_on) {
+                    queue_store(qout, rank < c0 ? b0 + rank : b1 + (rank - c0), id, r);
+                    rng_buf[id] = rng; // ScopedRng store: the next bounce's launch reads the word back
+                }
             }
         }
         refill.round(slot_finished);
@@ -1018,6 +1104,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         atomicAdd(stats_out + 4, (unsigned long long)ws.shade_rounds), atomicAdd(stats_out + 5, (unsigned long long)ws.shade_lanes);
         atomicAdd(stats_out + 6, (unsigned long long)ws.live_lane_steps), atomicAdd(stats_out + 7, (unsigned long long)ws.top_lanes);
     }
+    leave();
 }
 
 // ---- K6 + K7: mean over samples, sqrt gamma, fp32 + unorm8 outputs ------------------------------------

@@ -18,7 +18,14 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
+// RT_WITH_TS=1 (the experiment library librt_exp_ts.so only, never the product): k_megakernel_ts, traversal and shading waves decoupled
+// through LDS slot queues (rt_kernel_ts.h; measured 4.1 against 7.05 Grays/s), selected at run time with RT_MEGA_TS=1
+#ifndef RT_WITH_TS
+#define RT_WITH_TS 0
+#endif
+#if RT_WITH_TS
 #include "rt_kernel_ts.h"
+#endif
 #include "scene_build.h"
 
 using namespace rt;
@@ -195,7 +202,7 @@ struct rt_renderer {
     //   their paths; >= max_depth = the reference's schedule (a launch pair per bounce).
     //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
     //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
-    rt_schedule sched{RT_WF_FINISH_DEPTH_DEFAULT, RT_WF_SAMPLES_PER_LAUNCH_DEFAULT, 0u, -1, 0u, 0u, -1, 0u};
+    rt_schedule sched{RT_WF_FINISH_DEPTH_DEFAULT, RT_WF_SAMPLES_PER_LAUNCH_DEFAULT, 0u, -1, 0u, 0u, -1, 0u, 0u};
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC, tuning)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
@@ -216,8 +223,10 @@ struct rt_renderer {
     uint32_t mega_lds_pad = 0, mega_occ = RT_MEGA_WAVES;
     // RT_MEGA_TS=1: k_megakernel_ts (traversal and shading decoupled inside every workgroup, rt_kernel_ts.h) instead of k_megakernel
     bool mega_ts = false;
+#if RT_WITH_TS
     TsSlots ts_slots{};
     uint32_t ts_blocks = 0;
+#endif
 };
 
 namespace {
@@ -234,7 +243,9 @@ void free_tile_buffers(rt_renderer* r) {
         p = nullptr;
     };
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
+#if RT_WITH_TS
     fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
+#endif
     for (auto& L : r->lanes) {
         fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra), fr(L.d_cost), fr(L.d_tile_key), fr(L.d_tile_order);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
@@ -283,7 +294,12 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
 // pixel kept in its lane for all its samples (rt_kernels.h): rt_schedule{finish_depth 0, samples_per_launch 0}.
 bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch == 0 && r->sched.finish_depth == 0 && r->max_depth > 0; }
 // stream lanes (interleaved sub-tiles on HIP streams of their own): 1 for the one-launch schedule, 2 where launches have tails to overlap
-uint32_t wf_stream_lanes(const rt_renderer* r) { return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : 2u); }
+// (three for the split EXTEND + SHADE pipeline of every bounce: 1 / 2 / 3 lanes 4234 / 5126 / 5317 Mrays/s on the atrium at 1080p, 16 spp)
+uint32_t wf_stream_lanes(const rt_renderer* r) {
+    if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u);
+    if (wf_one_launch(r)) return 1u;
+    return r->sched.finish_depth >= r->max_depth && !r->sched.fused_bounce ? 3u : 2u;
+}
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
 bool wf_spread(const rt_renderer* r) {
@@ -336,6 +352,7 @@ int alloc_tile_buffers(rt_renderer* r) {
     HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors + error word
+#if RT_WITH_TS
         if (r->mega_ts) {
             const uint32_t tiles = (uint32_t)((r->width + 7) / 8) * (uint32_t)((r->tile.local_rows + 7) / 8);
             r->ts_blocks = std::max<uint32_t>(1u, std::min<uint32_t>((tiles + 7u) / 8u, (uint32_t)r->n_cus * 3u)); // three workgroups per CU
@@ -346,6 +363,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             HIPCHK(hipMalloc((void**)&r->ts_slots.color_s, ns * 16));
             HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
         }
+#endif
     } else {
         const uint32_t K = wf_stream_lanes(r);
         const bool per_bounce = r->sched.finish_depth > 0 && r->max_depth > 0; // EXTEND + SHADE launch pairs: the second queue and the hit records
@@ -357,16 +375,18 @@ int alloc_tile_buffers(rt_renderer* r) {
             L.tile.local_rows = rows_of_tile(L.tile, r->height);
             L.n_local = (uint32_t)L.tile.local_rows * (uint32_t)r->width;
             const size_t m = std::max<size_t>(L.n_local, 1);
+            // SHOOT launches reserve the next queue in blocks of kOutBlock slots per workgroup: up to one partly used block per workgroup
+            const size_t mq = m + (per_bounce && r->sched.fused_bounce ? (size_t)kOutBlock * ((size_t)r->n_cus * 4u * RT_MEGA_WAVES / (RT_MEGA_BLOCK / 64) + 1u) : 0u);
             for (int qi = 0; qi < (per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
                 auto& q = L.q[qi];
-                HIPCHK(hipMalloc((void**)&q.org_id, m * 16));
-                HIPCHK(hipMalloc((void**)&q.a, m * 8));
-                HIPCHK(hipMalloc((void**)&q.b, m * 8));
-                HIPCHK(hipMalloc((void**)&q.c, m * 2 + 2));
+                HIPCHK(hipMalloc((void**)&q.org_id, mq * 16));
+                HIPCHK(hipMalloc((void**)&q.a, mq * 8));
+                HIPCHK(hipMalloc((void**)&q.b, mq * 8));
+                HIPCHK(hipMalloc((void**)&q.c, mq * 2 + 2));
             }
             HIPCHK(hipMalloc((void**)&L.d_rng, m * 4));
             HIPCHK(hipMalloc((void**)&L.d_accum, m * 16));
-            if (per_bounce) HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
+            if (per_bounce && !r->sched.fused_bounce) HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
             const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
             // spp * (max_depth + 1) queue lengths, spp * max_depth chunk cursors, spp "extra ray" counters of k_wf_finish
             HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
@@ -452,6 +472,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         if (r->lanes[k].n_local) chunk = std::min(chunk, wf_chunk(r, r->lanes[k].n_local));
     // cost ordering (one-launch schedule, one stream lane): sample 0 in a launch of its own, then all the others, most expensive blocks first
     const bool lpt = K == 1 && r->lanes[0].n_tiles != 0 && chunk == r->spp && D0 == 0 && D > 0;
+    const bool shoot_frame = r->sched.fused_bounce && D0 > 0; // queues may hold holes: every launch counts its rays on the device
     for (uint32_t s = 0; s < r->spp;) {
         const uint32_t n_samples = lpt ? (s == 0 ? 1u : r->spp - 1u) : std::min(chunk, r->spp - s);
         const bool ordered = lpt && s > 0;
@@ -475,6 +496,35 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 hipStream_t ls = lane_stream(L);
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
+                if (r->sched.fused_bounce) { // SHOOT: intersect + shade + compact in ONE launch per bounce (k_wf_finish<.., LIMIT> with a limit of one bounce)
+                    constexpr uint32_t fin_wpb = RT_MEGA_BLOCK / 64;
+                    const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
+                    const uint32_t chunk_slots = L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk;
+                    const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + chunk_slots - 1u) / chunk_slots, fin_cap));
+                    const uint32_t fin_grid = (fin_waves + fin_wpb - 1u) / fin_wpb;
+                    hipEvent_t f0 = nullptr, f1 = nullptr;
+                    if (r->profile_kernels) {
+                        f0 = pool_event(L.ev_pool, ne[k]), f1 = pool_event(L.ev_pool, ne[k] + 1);
+                        if (!f0 || !f1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                        HIPCHK(hipEventRecord(f0, ls));
+                    }
+                    const FinishRequeue no_fq{nullptr, nullptr, nullptr, 0u};
+#define RT_SHOOT_LAUNCH(ST)                                                                                                                  \
+    hipLaunchKernelGGL((k_wf_finish<ST, false, true>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + d,    \
+                       cursors + (size_t)s * D + d, L.d_rng, L.d_accum, L.d_extra + s, d, D, 1u, r->rr_start,                                 \
+                       ST ? r->d_stats : (unsigned long long*)nullptr, no_fq, chunk_slots, (uint8_t*)nullptr, L.q[buf[k] ^ 1], counts + d + 1, 1u, 1u)
+                    if (r->d_stats) RT_SHOOT_LAUNCH(true);
+                    else RT_SHOOT_LAUNCH(false);
+#undef RT_SHOOT_LAUNCH
+                    if (r->profile_kernels) {
+                        HIPCHK(hipEventRecord(f1, ls));
+                        L.spans.push_back({(uint32_t)ne[k], (uint32_t)ne[k] + 1, RT_K_WF_SHOOT});
+                        ne[k] += 2;
+                    }
+                    launches.add(RT_K_WF_SHOOT);
+                    buf[k] ^= 1;
+                    continue;
+                }
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr; // profiling: e0 EXTEND e1 SHADE e2
                 if (r->profile_kernels) {
                     e0 = pool_event(L.ev_pool, ne[k]), e1 = pool_event(L.ev_pool, ne[k] + 1), e2 = pool_event(L.ev_pool, ne[k] + 2);
@@ -545,7 +595,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
     hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
                        cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
-                       ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots, lpt && s == 0 ? L.d_cost : (uint8_t*)nullptr)
+                       ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots, lpt && s == 0 ? L.d_cost : (uint8_t*)nullptr, QueueDev{}, (uint32_t*)nullptr, 0u,     \
+                       shoot_frame ? 1u : 0u)
                 if (r->d_stats && req) RT_FINISH_LAUNCH(true, true);
                 else if (r->d_stats) RT_FINISH_LAUNCH(true, false);
                 else if (req) RT_FINISH_LAUNCH(false, true);
@@ -613,6 +664,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipEventRecord(e0, st));
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
+#if RT_WITH_TS
         } else if (r->mega_ts) {
             if (r->d_stats) {
                 HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
@@ -622,6 +674,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                 hipLaunchKernelGGL(k_megakernel_ts<false>, dim3(r->ts_blocks), dim3(kTsBlock), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode,
                                    r->rr_start, d_f32, d_u8, r->d_ray_counter, r->ts_slots, (unsigned long long*)nullptr);
             }
+#endif
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
@@ -735,7 +788,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
         }
     } else {
         // the dominant kernel of the schedule that ran: k_wf_extend where every bounce is a launch pair, k_wf_finish otherwise
-        const int hot = std::min(r->max_depth, r->sched.finish_depth) >= r->max_depth && r->max_depth > 0 ? RT_K_WF_EXTEND : RT_K_WF_FINISH;
+        const int hot = std::min(r->max_depth, r->sched.finish_depth) >= r->max_depth && r->max_depth > 0 ? (r->sched.fused_bounce ? RT_K_WF_SHOOT : RT_K_WF_EXTEND) : RT_K_WF_FINISH;
         for (auto& L : r->lanes)
             for (const auto& sp : L.spans) {
                 float k = 0.0f;
@@ -758,9 +811,11 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(L.h_extra.data(), L.d_extra, L.h_extra.size() * 8, hipMemcpyDeviceToHost));
                 if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: the dynamic queue stalled or overflowed (internal error word set)");
+                const bool shoot_frame = r->sched.fused_bounce && std::min(D, r->sched.finish_depth) > 0; // SHOOT queues have holes: counted on the device
                 for (uint32_t s = 0; s < r->spp; ++s) {
-                    for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407 (queue lengths)
-                    rays += L.h_extra[s];                                                        // rays k_wf_finish traced beyond a queue
+                    if (!shoot_frame)
+                        for (uint32_t d = 0; d < D; ++d) rays += L.h_counts[(size_t)s * (D + 1) + d]; // :407 (queue lengths)
+                    rays += L.h_extra[s];                                                            // rays k_wf_finish traced beyond a queue
                 }
             }
             local.rays = rays;
@@ -874,6 +929,25 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
     if (device >= 0) {
         rc = device_ok(device);
         if (rc == RT_OK) rc = upload(s->hs.nodes, &s->dev.nodes, s->device_bytes);
+#if RT_WIDE_NODES
+        if (rc == RT_OK) {
+            std::vector<WideNode> wide(s->hs.nodes.size());
+            for (size_t i = 0; i < wide.size(); ++i) {
+                const BvhNode& n = s->hs.nodes[i];
+                WideNode& w = wide[i];
+                std::memset(&w, 0, sizeof(w));
+                for (int k = 0; k < 4; ++k) {
+                    for (int a = 0; a < 3; ++a) {
+                        const float lo = n.origin[a] + (float)((n.q[2 * a] >> (8 * k)) & 0xffu) * n.scale(a);
+                        const float hi = n.origin[a] + (float)((n.q[2 * a + 1] >> (8 * k)) & 0xffu) * n.scale(a);
+                        w.plane[2 * a][k] = std::nextafter(lo, -INFINITY), w.plane[2 * a + 1][k] = std::nextafter(hi, INFINITY);
+                    }
+                    w.child[k] = n.child[k] >= 0 ? n.child[k] * 128 : n.child[k];
+                }
+            }
+            rc = upload(wide, &s->dev.wnodes, s->device_bytes);
+        }
+#endif
         if (rc == RT_OK) rc = upload(s->hs.tris, &s->dev.tris, s->device_bytes);
         if (rc == RT_OK) rc = upload(s->hs.shade, &s->dev.shade, s->device_bytes);
         if (rc == RT_OK) rc = upload(s->hs.inst, &s->dev.inst, s->device_bytes);
@@ -899,7 +973,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
-        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
+        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.wnodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
         (void)hipFree((void*)s->dev.inst), (void)hipFree((void*)s->dev.mats), (void)hipFree((void*)s->dev.tex);
     }
     delete s;
@@ -976,7 +1050,9 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
+#if RT_WITH_TS
     if (const char* e = std::getenv("RT_MEGA_TS")) r->mega_ts = e[0] == '1' && kind == RT_RENDERER_MEGAKERNEL;
+#endif
     if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
@@ -1004,6 +1080,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) sc.reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_FUSED_BOUNCE")) sc.fused_bounce = e[0] == '1';
     }
     rc = no_throw([&] { return alloc_tile_buffers(r); });
     if (rc != RT_OK) return bail(rc);
@@ -1067,7 +1144,7 @@ int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out) {
 int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
     if (!r || !s) return fail(RT_ERR_INVALID, "null argument");
     if (s->stream_lanes > 8) return fail(RT_ERR_INVALID, "at most 8 stream lanes");
-    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1)
+    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1 || s->fused_bounce > 1)
         return fail(RT_ERR_INVALID, "schedule field out of range");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     if (r->kind != RT_RENDERER_WAVEFRONT) return RT_OK; // the megakernel is one launch: nothing to schedule

@@ -31,6 +31,24 @@ struct alignas(64) BvhNode {
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 constexpr int32_t kChildEmpty = (int32_t)0x80000000;
 
+// RT_WIDE_NODES=1: the traversal kernels read the SAME tree from 128-byte nodes whose child boxes are fp32 planes, grouped so that the
+// four children's planes of one (axis, side) are one 16-byte word: a ray picks its near / far planes by ADDRESS (offset 0 / 16 within
+// the axis' 32 bytes, fixed per ray) instead of selecting packed bytes, and needs no byte -> float conversions: per inner step 24
+// v_cvt_f32_ubyte, 6 v_cndmask and 3 v_cmp (all half-rate instructions) and the 6 setup multiplies go, 7 sixteen-byte loads replace 4.
+//   bytes 0-15 lo_x[4], 16-31 hi_x[4], 32-47 lo_y[4], 48-63 hi_y[4], 64-79 lo_z[4], 80-95 hi_z[4], 96-111 child[4], 112-127 unused
+// child >= 0: BYTE offset of the child node (index * 128); child < 0: the leaf code of BvhNode. Derived on the host from the quantised
+// nodes (planes decoded, lo rounded down / hi up), so both formats cull identically; the quantised array stays the canonical tree
+// (rt_scene_check_bvh, rt_scene_info).
+#ifndef RT_WIDE_NODES
+#define RT_WIDE_NODES 0
+#endif
+struct alignas(128) WideNode {
+    float plane[6][4];
+    int32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
+
 #ifndef RT_MAX_LEAF_TRIS
 #define RT_MAX_LEAF_TRIS 4
 #endif
@@ -84,6 +102,7 @@ static_assert(sizeof(MatRec) == 48, "MatRec must be 48 bytes");
 // device pointers of one scene replica
 struct SceneDev {
     const BvhNode* nodes;
+    const WideNode* wnodes; // RT_WIDE_NODES builds only (else null)
     const TriRec* tris;
     const ShadeRec* shade;
     const InstRec* inst;

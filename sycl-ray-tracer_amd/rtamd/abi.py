@@ -91,7 +91,7 @@ class rt_scene_info_t(C.Structure):
 RT_SCHED_ALL_BOUNCES = 0xFFFFFFFF
 # kernel families of rt_stats.launches_by_kernel (include/rt_mi355x.h)
 KERNELS = {"megakernel": 0, "wf_init": 1, "wf_generate": 2, "wf_extend": 3, "wf_shade": 4, "wf_shade_reorder": 5, "wf_shade_matsort": 6,
-           "wf_finish": 7, "wf_finish_requeue": 8, "wf_tile_order": 9, "wf_resolve": 10, "fill_black": 11}
+           "wf_finish": 7, "wf_finish_requeue": 8, "wf_tile_order": 9, "wf_resolve": 10, "fill_black": 11, "wf_shoot": 12}
 RT_K_COUNT = 16
 
 
@@ -105,6 +105,7 @@ class rt_schedule(C.Structure):
         ("matsort", C.c_uint32),
         ("cost_order", C.c_int32),
         ("hip_graph", C.c_uint32),
+        ("fused_bounce", C.c_uint32),
     ]
 
 

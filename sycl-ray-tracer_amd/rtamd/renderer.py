@@ -145,12 +145,13 @@ class IRenderer:
         abi.check(self._lib.rt_renderer_set_russian_roulette(self.h, int(start_bounce)))
 
     def set_schedule(self, finish_depth: int = 0, samples_per_launch: int = 0, stream_lanes: int = 0, requeue: int = -1,
-                     reorder: bool = False, matsort: bool = False, cost_order: int = -1, hip_graph: bool = False) -> None:
+                     reorder: bool = False, matsort: bool = False, cost_order: int = -1, hip_graph: bool = False,
+                     fused_bounce: bool = False) -> None:
         """rt_renderer_set_schedule: which of the wavefront renderer's schedules renders the frame (same frame bit for bit; the
         reference has one: a launch per bounce, src/render_wavefront.cpp:396-417 = finish_depth=abi.RT_SCHED_ALL_BOUNCES).
         Frame.kernels reports what ran. The megakernel ignores it."""
         sc = abi.rt_schedule(int(finish_depth), int(samples_per_launch), int(stream_lanes), int(requeue), int(bool(reorder)),
-                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)))
+                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(bool(fused_bounce)))
         abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)))
 
     def get_schedule(self) -> abi.rt_schedule:

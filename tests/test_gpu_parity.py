@@ -311,38 +311,6 @@ def test_native_frame_gather_equals_the_single_device_frame(gpu_scenes, oracle, 
     comm.close()
 
 
-def test_megakernel_with_decoupled_shading_waves_keeps_the_frame(gpu_scenes, oracle, monkeypatch):
-    """RT_MEGA_TS=1: k_megakernel_ts — seven traversal waves and one shading wave per workgroup exchange pixel slots through two LDS
-    queues (rt_kernel_ts.h). A pixel's rays are still traced and shaded one after the other, by different lanes: frame, unorm8 image
-    and ray count must equal the oracle's MegakernelRenderer — tiny frames (fewer pixels than one workgroup has slots), frames that
-    are not a multiple of the 8x8 tiles, odd tile splits, Russian roulette, max_depth 1, and the same renderer twice."""
-    monkeypatch.setenv("RT_MEGA_TS", "1")
-    cases = (("cube", {}, (1, 1), 5, 2), ("cube", {}, (37, 21), 1, 3), ("cornell", {}, (96, 64), 8, 4), ("atrium", {"detail": 1}, (256, 144), 10, 3),
-             ("cornell", {}, (333, 187), 6, 2))
-    for name, kw, (w, h), depth, spp in cases:
-        gs = gpu_scenes(name, **kw)
-        sd = gs.desc
-        cam = Camera.for_scene(sd, (w, h))
-        ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
-        osc = oracle.OracleScene(sd)
-        r = MegakernelRenderer(gs, (w, h), depth, spp)
-        for rep in range(2):
-            got = r.render_frame(cam)
-            f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"))
-            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {w}x{h} ts rep {rep}")
-        r.set_russian_roulette(2)
-        got = r.render_frame(cam)
-        f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"), rr_start=2)
-        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} ts rr")
-        r.set_russian_roulette(0)
-        if h >= 24:
-            r.set_tile(1, 3, 8)
-            tile = r.render_frame(cam)
-            f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=(name == "atrium"), rank=1, world=3, strip_rows=8)
-            _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} ts tile 1/3")
-        r.close()
-
-
 ALL_BOUNCES = abi.RT_SCHED_ALL_BOUNCES
 
 
@@ -393,7 +361,8 @@ def test_wavefront_streaming_samples_keep_the_frame(gpu_scenes, oracle, samples_
 
 SCHEDULES = [dict(samples_per_launch=1, stream_lanes=2), dict(samples_per_launch=1, stream_lanes=3), dict(samples_per_launch=1, requeue=0),
              dict(stream_lanes=1, samples_per_launch=2), dict(stream_lanes=4, samples_per_launch=3, requeue=1), dict(finish_depth=2, stream_lanes=1),
-             dict(stream_lanes=2), dict(stream_lanes=3, cost_order=1), dict(finish_depth=ALL_BOUNCES, stream_lanes=1), dict(finish_depth=ALL_BOUNCES, hip_graph=True)]
+             dict(stream_lanes=2), dict(stream_lanes=3, cost_order=1), dict(finish_depth=ALL_BOUNCES, stream_lanes=1), dict(finish_depth=ALL_BOUNCES, hip_graph=True),
+             dict(finish_depth=ALL_BOUNCES, fused_bounce=True), dict(finish_depth=ALL_BOUNCES, fused_bounce=True, stream_lanes=1), dict(finish_depth=3, fused_bounce=True, stream_lanes=3)]
 
 
 @pytest.mark.parametrize("sched", SCHEDULES, ids=lambda e: ",".join(f"{k}={v if v != ALL_BOUNCES else 'all'}" for k, v in e.items()))
@@ -410,10 +379,14 @@ def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, sched):
         back = r.get_schedule()
         assert all(getattr(back, k) == int(v) for k, v in sched.items())
         got = r.render_frame(cam)
-        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else 2)
+        # automatic stream lanes: 1 for the one-launch schedule, 3 where every bounce is an EXTEND + SHADE pair, else 2
+        auto = 1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else (3 if sched.get("finish_depth", 0) >= depth and not sched.get("fused_bounce") else 2)
+        lanes = sched.get("stream_lanes", 0) or auto
         assert got.stream_lanes == lanes and got.finish_depth == min(sched.get("finish_depth", 0), depth)
         assert got.kernels["wf_init"] == got.kernels["wf_resolve"] == lanes
-        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == lanes * spp * got.finish_depth
+        fused = bool(sched.get("fused_bounce"))  # one SHOOT launch per bounce instead of the EXTEND + SHADE pair
+        assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == (0 if fused else lanes * spp * got.finish_depth)
+        assert got.kernels["wf_shoot"] == (lanes * spp * got.finish_depth if fused else 0)
         assert (got.kernels["wf_finish"] > 0) == (got.finish_depth < depth)
         assert sum(got.kernels.values()) - got.kernels["wf_shade_reorder"] - got.kernels["wf_shade_matsort"] - got.kernels["wf_finish_requeue"] == got.launches
         f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
@@ -433,7 +406,7 @@ def test_schedule_environment_shim_maps_onto_the_api(gpu_scenes, oracle, monkeyp
     w, h, depth, spp = 96, 64, 6, 4
     cam = Camera.for_scene(sd, (w, h))
     f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp)
-    cases = [({"RT_WF_FINISH_DEPTH": "99", "RT_WF_REORDER": "1"}, dict(finish_depth=99, reorder=1), ("wf_shade_reorder", 2 * spp * depth)),
+    cases = [({"RT_WF_FINISH_DEPTH": "99", "RT_WF_REORDER": "1"}, dict(finish_depth=99, reorder=1), ("wf_shade_reorder", 3 * spp * depth)),
              ({"RT_WF_STREAMS": "3"}, dict(stream_lanes=3, samples_per_launch=1), ("wf_finish", 3 * spp)),
              ({"RT_WF_REQUEUE": "0"}, dict(requeue=0, samples_per_launch=1), ("wf_finish", 2 * spp)),
              ({"RT_WF_SAMPLES_PER_LAUNCH": "2"}, dict(samples_per_launch=2), ("wf_finish_requeue", 2 * 2)),
@@ -468,7 +441,7 @@ def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, finish_depth
         r.set_schedule(finish_depth=finish_depth)
         got = r.render_frame(cam)
         d0 = min(finish_depth, depth)
-        lanes = 1 if finish_depth == 0 else 2
+        lanes = 1 if finish_depth == 0 else (3 if d0 == depth else 2)
         assert got.finish_depth == d0 and got.stream_lanes == lanes
         assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == lanes * spp * d0
         assert got.kernels["wf_finish"] == (0 if d0 == depth else lanes * (spp if d0 else 1))
@@ -748,6 +721,12 @@ def test_baseline_configs_at_full_size(gpu_scenes, scene_cache, oracle, name, kw
         np.testing.assert_array_equal(pb.rgba_f32, a.rgba_f32)
         np.testing.assert_array_equal(pb.rgba_u8, a.rgba_u8)
         frames.append(("per-bounce schedule", pb.rgba_f32, pb.rgba_u8))
+        r.set_schedule(finish_depth=ALL_BOUNCES, fused_bounce=True)  # ... and as ONE kernel per bounce (intersect + shade + compact)
+        fb = r.render_frame(cam)
+        assert fb.kernels["wf_shoot"] == fb.stream_lanes * spp * depth and fb.kernels["wf_extend"] == fb.kernels["wf_finish"] == 0
+        assert fb.rays == a.rays
+        np.testing.assert_array_equal(fb.rgba_f32, a.rgba_f32)
+        frames.append(("fused per-bounce schedule", fb.rgba_f32, fb.rgba_u8))
     r.close()
     _assert_strips_equal_the_oracle(oracle, sd, kind, w, h, depth, spp, frames, strips, what=f"{name} {w}x{h} {spp}spp {cls.__name__}")
 
@@ -785,6 +764,12 @@ def test_config5_as_stated_tile_0_of_8(gpu_scenes, scene_cache, oracle, cls, kin
         assert pb.rays == a.rays
         np.testing.assert_array_equal(pb.rgba_f32, a.rgba_f32)
         frames.append(("per-bounce schedule", pb.rgba_f32, pb.rgba_u8))
+        r.set_schedule(finish_depth=ALL_BOUNCES, fused_bounce=True)
+        fb = r.render_frame(cam)
+        assert fb.kernels["wf_shoot"] == fb.stream_lanes * spp * depth and fb.kernels["wf_extend"] == fb.kernels["wf_finish"] == 0
+        assert fb.rays == a.rays
+        np.testing.assert_array_equal(fb.rgba_f32, a.rgba_f32)
+        frames.append(("fused per-bounce schedule", fb.rgba_f32, fb.rgba_u8))
     r.close()
     np.testing.assert_array_equal(a.rgba_u8[..., :3], np.rint(np.clip(a.rgba_f32[..., :3], 0, 1) * 255).astype(np.uint8))
     # global strips 64 and 200 belong to rank 0 (64 % 8 == 200 % 8 == 0) and are its local strips 8 and 25
