@@ -192,7 +192,11 @@ def main() -> int:
         if name.startswith("wavefront_per_bounce"):
             r.set_schedule(finish_depth=abi.RT_SCHED_ALL_BOUNCES, fused_bounce=name.endswith("fused"))
         r.set_tile(rank, world, strip)
-        r.set_profiling(True)  # per-launch hipEvents of the traversal / shading kernels, on the launches' own streams
+        # per-launch hipEvents of the traversal / shading kernels, on the launches' own streams, INSIDE the timed region — for the
+        # renderers with one such launch per frame. The per-bounce schedules have ~1,300 - 3,800 launches per frame: three event records
+        # per launch pair on three streams slow them by a third (measured: 5.3 -> 3.1 Grays/s), so their timed frames run without events
+        # and ONE more frame with events, after the timed region, supplies the per-kernel durations of their roofline objects.
+        r.set_profiling(not name.startswith("wavefront_per_bounce"))
         return r
 
     def measure(name, F=F0):
@@ -246,6 +250,12 @@ def main() -> int:
         barrier()
         elapsed = time.perf_counter() - t0
         rows = fg.rows
+        kernel_frames = args.steps
+        if rs and name.startswith("wavefront_per_bounce"):  # the per-kernel durations: one profiled frame outside the timed region
+            rs[0].set_profiling(True)
+            fr = rs[0].render_frame_device(cam, d_f32=fgs[0].local.data_ptr())
+            tot["kernel_ms"], tot["hot_ms"], tot["hot_launches"], kernel_frames = dict(fr.kernel_ms), fr.hot_kernel_ms, fr.hot_kernel_launches, 1
+            tot["profiled_rays"] = fr.rays
         for r in rs:
             r.close()
         rays_all, own_ms = float(tot["rays"]), elapsed * 1e3
@@ -264,7 +274,7 @@ def main() -> int:
                "per_rank_ms": per_rank_ms, "gather_ms": round(tot["gather_s"] / args.steps * 1e3, 3)}
         if not rehearsal:
             res["launches_per_frame"] = {k: v // args.steps for k, v in tot["kernels"].items() if v}
-            res["roofline"] = roofline_of(name, args, tot, rows, W, rays_all, elapsed)
+            res["roofline"] = roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames)
         return res
 
     if rehearsal:
@@ -316,11 +326,11 @@ def main() -> int:
     return 0
 
 
-def roofline_of(name, args, tot, rows, W, rays_all, elapsed):
+def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
     """The contractual roofline object of one renderer on THIS rank: algorithmic bytes per launch of its dominant kernel / that
     kernel's mean launch duration (hipEvents on the launch's own stream) against the HBM peak."""
     hot_launches, hot_ms = tot["hot_launches"], tot["hot_ms"]
-    rays = tot["rays"]
+    rays = tot.get("profiled_rays", tot["rays"])  # rays of the frames the kernel durations were taken over
     if name == "wavefront":
         kernel, bytes_per_launch = "k_wf_finish<false, false, false>", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
     elif name == "wavefront_per_bounce":
@@ -338,18 +348,19 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed):
         # both kernels of the pipeline, each against its own algorithmic bytes; the launches of the two stream lanes overlap, so the
         # per-kernel sums are device time of a lane, not wall time
         ext_s, shd_s = tot["kernel_ms"].get("wf_extend", 0.0) * 1e-3, tot["kernel_ms"].get("wf_shade", 0.0) * 1e-3
-        n_pairs = max(tot["kernels"].get("wf_shade", 0), 1)
+        n_pairs = max(tot["kernels"].get("wf_shade", 0) // max(args.steps, 1) * kernel_frames, 1)
         roof["pipeline"] = {
             "bytes_per_ray": EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY,
             "achieved_gbs_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9, 3),
             "frac_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9 / HBM_PEAK_GBS, 6),
-            "k_wf_extend": {"bytes_per_ray": EXTEND_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(ext_s * 1e3 / args.steps, 3),
+            "k_wf_extend": {"bytes_per_ray": EXTEND_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(ext_s * 1e3 / kernel_frames, 3),
                             "achieved_gbs": round(EXTEND_BYTES_PER_RAY * rays / ext_s / 1e9, 3) if ext_s else None},
-            "k_wf_shade": {"bytes_per_ray": SHADE_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(shd_s * 1e3 / args.steps, 3),
+            "k_wf_shade": {"bytes_per_ray": SHADE_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(shd_s * 1e3 / kernel_frames, 3),
                            "mean_launch_ms": round(shd_s * 1e3 / n_pairs, 5),
                            "achieved_gbs": round(SHADE_BYTES_PER_RAY * rays / shd_s / 1e9, 3) if shd_s else None,
                            "frac": round(SHADE_BYTES_PER_RAY * rays / shd_s / 1e9 / HBM_PEAK_GBS, 6) if shd_s else None},
-            "stream_lanes": tot["lanes"], "launch_pairs_per_frame": n_pairs // args.steps,
+            "stream_lanes": tot["lanes"], "launch_pairs_per_frame": n_pairs // kernel_frames,
+            "kernel_durations_from": "one frame with per-launch hipEvents rendered after the timed region (events on ~3,800 launches slow the timed frames by a third)",
             "note": "the reference's shape: per sample and bounce one EXTEND + one SHADE launch, survivors compacted between bounces (wave ballot + mbcnt "
                     "prefix, one atomic per 256-thread block); two interleaved sub-tiles on two HIP streams overlap one lane's launch tails with the other's traversal"}
     elif name == "wavefront_per_bounce_fused":

@@ -8,7 +8,8 @@ from rtamd.renderer import Scene, Camera, MegakernelRenderer, WavefrontRenderer
 CASES = [("cube 512x512 16spp d10", scenes.cube_scene, {}, 512, 512, 16, 10, 1),
          ("cornell 1024x1024 64spp d10", scenes.cornell_scene, {}, 1024, 1024, 64, 10, 1),
          ("atrium 1920x1080 64spp d10", scenes.atrium_scene, {"detail": 4}, 1920, 1080, 64, 10, 1),
-         ("atrium 3840x2160 256spp d16, tile 1/8", scenes.atrium_scene, {"detail": 4}, 3840, 2160, 256, 16, 8)]
+         ("atrium 3840x2160 256spp d16, tile 1/8", scenes.atrium_scene, {"detail": 4}, 3840, 2160, 256, 16, 8),
+         ("voxel terrain 1920x1080 128spp d10", scenes.voxel_scene, {"detail": 4}, 1920, 1080, 128, 10, 1)]  # the reference's minecraft.glb row (benchmark_avg.csv:20-21)
 for label, fn, kw, w, h, spp, depth, world in CASES:
     sd = fn(**kw); sc = Scene(sd, 0); cam = Camera.for_scene(sd, (w, h))
     for cls in (WavefrontRenderer, MegakernelRenderer):

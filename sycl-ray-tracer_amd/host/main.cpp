@@ -4,6 +4,8 @@
 //   -w,--wavefront         -m,--megakernel        neither => wavefront
 // Extensions (the reference hard-codes 1920x1080, one device, out.png):
 //   --width N --height N   --device N   --devices A,B,..   --out FILE   --bvh {sah,lbvh}   --rr N   --quiet
+//   --schedule {default,per-sample,per-bounce,per-bounce-fused}   which of the wavefront renderer's schedules renders the frame
+//                          (rt_renderer_set_schedule; per-bounce = the reference's own: src/render_wavefront.cpp:396-417)
 // Prints the same lines as the reference (Loading scene, loader chatter, Sample n, the three statistics
 // lines benchmark.py scrapes, Writing image to disk) and writes the PNG.
 #include <cstdio>
@@ -29,6 +31,8 @@ static void usage(const char* argv0) {
                 "  --out FILE                  Output PNG (default out.png)\n"
                 "  --bvh sah|lbvh              BVH builder (default sah)\n"
                 "  --rr UINT                   Russian roulette from this bounce on (default 0 = off, as the reference)\n"
+                "  --schedule NAME             wavefront schedule: default (one launch per frame), per-sample, per-bounce (a launch pair per\n"
+                "                              bounce with compaction in between, the reference's), per-bounce-fused (one kernel per bounce)\n"
                 "  --quiet                     No loader chatter\n",
                 argv0);
 }
@@ -41,6 +45,8 @@ int main(int argc, const char* argv[]) {
     int device = 0, bvh = RT_BVH_DEFAULT;
     std::vector<int> devices;
     bool have_scene = false;
+    rt_schedule schedule{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u}; // the library's default
+    bool schedule_given = false;
 
     auto need = [&](int& i) -> const char* {
         if (i + 1 >= argc) {
@@ -84,6 +90,15 @@ int main(int argc, const char* argv[]) {
         else if (a == "--out") out_path = need(i);
         else if (a == "--rr") rr = to_u32("--rr", need(i));
         else if (a == "--quiet") quiet = true;
+        else if (a == "--schedule") {
+            const std::string v = need(i);
+            schedule_given = true;
+            if (v == "default") schedule_given = false;
+            else if (v == "per-sample") schedule.samples_per_launch = 1;
+            else if (v == "per-bounce") schedule.finish_depth = RT_SCHED_ALL_BOUNCES;
+            else if (v == "per-bounce-fused") schedule.finish_depth = RT_SCHED_ALL_BOUNCES, schedule.fused_bounce = 1;
+            else { std::fprintf(stderr, "--schedule: expected default, per-sample, per-bounce or per-bounce-fused\n"); return 105; }
+        }
         else if (a == "--bvh") {
             const std::string v = need(i);
             if (v == "sah") bvh = RT_BVH_SAH;
@@ -130,6 +145,7 @@ int main(int argc, const char* argv[]) {
             r->out_path = out_path;
             r->russian_roulette = rr;
             r->devices = devices;
+            if (schedule_given) r->schedule = schedule, r->has_schedule = true;
             renderer.reset(r);
         }
         renderer->render_frame(camera, scene);

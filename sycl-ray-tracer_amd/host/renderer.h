@@ -88,6 +88,10 @@ struct HipRendererBase : public IRenderer {
     int kind;
     std::string out_path = "out.png"; // src/util.hpp:27
     uint32_t russian_roulette = 0;    // extension, 0 = off (rt_renderer_set_russian_roulette)
+    // Extension: which of the wavefront renderer's schedules renders the frame (rt_renderer_set_schedule; same frame bit for bit). The
+    // reference has one, a launch per bounce (src/render_wavefront.cpp:396-417): finish_depth = RT_SCHED_ALL_BOUNCES. Ignored by the megakernel.
+    rt_schedule schedule{};
+    bool has_schedule = false;
     // Extension: more than one entry tiles the frame over these HIP devices in THIS process, one host thread per
     // tile (interleaved 8-row strips, tile k -> devices[k]; the same device may appear more than once). Every tile is
     // rendered into its renderer's own device buffer; rt_frame_gather then brings the strips to devices[0] with one
@@ -116,6 +120,7 @@ struct HipRendererBase : public IRenderer {
                 rt_check(rt_renderer_create(kind, scene.on_device(devices[k]), img_size[0], img_size[1], max_depth, sample_count,
                                             RT_SEED_DEFAULT, &tile_handles[k]));
                 rt_check(rt_renderer_set_tile(tile_handles[k], k, G, 8));
+                if (has_schedule) rt_check(rt_renderer_set_schedule(tile_handles[k], &schedule));
             }
             bound = &scene;
         }
@@ -162,6 +167,7 @@ struct HipRendererBase : public IRenderer {
             rt_renderer_destroy(handle);
             handle = nullptr;
             rt_check(rt_renderer_create(kind, scene.handle, img_size[0], img_size[1], max_depth, sample_count, RT_SEED_DEFAULT, &handle));
+            if (has_schedule) rt_check(rt_renderer_set_schedule(handle, &schedule));
             bound = &scene;
         }
         rt_check(rt_renderer_set_russian_roulette(handle, russian_roulette));
@@ -177,6 +183,9 @@ struct HipRendererBase : public IRenderer {
         std::printf("Time measured: %.6f seconds\n", secs);
         std::printf("Total rays: %llu\n", (unsigned long long)last.rays);
         std::printf("Rays/sec: %.2fM\n", rays_per_sec / 1000000.0);
+        if (has_schedule && devices.size() <= 1) // what ran (rt_stats): launches of the traversal kernels of the frame
+            std::printf("Schedule: %u stream lanes, launches: extend %u, shade %u, shoot %u, finish %u\n", last.stream_lanes, last.launches_by_kernel[RT_K_WF_EXTEND],
+                        last.launches_by_kernel[RT_K_WF_SHADE], last.launches_by_kernel[RT_K_WF_SHOOT], last.launches_by_kernel[RT_K_WF_FINISH]);
         std::printf("Writing image to disk\n");
         if (!rthost::write_png_rgba8(out_path.c_str(), (uint32_t)img_size[0], (uint32_t)img_size[1], image, (size_t)img_size[0] * 4)) {
             std::printf("Failed to write image to disk.\n"); // src/util.hpp:27-30

@@ -99,3 +99,20 @@ def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, oracle, tm
     np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "three.png")), exp_u8)  # gathered on the device, equal to the oracle
     p = subprocess.run([str(EXE), "--devices", "0,99", "-s", "1", str(REPO / "assets" / "cube.glb")], capture_output=True, text=True, cwd=tmp_path)
     assert p.returncode == 1 and "does not exist" in p.stdout
+
+
+@pytest.mark.parametrize("schedule,expect", [("per-bounce", "extend 45, shade 45, shoot 0, finish 0"), ("per-bounce-fused", "extend 0, shade 0, shoot 30, finish 0"),
+                                             ("per-sample", "extend 0, shade 0, shoot 0, finish 6")])
+def test_cli_schedule_flag_selects_and_reports_the_schedule(rtlib, oracle, tmp_path, schedule, expect):
+    """--schedule: the wavefront renderer's other schedules through the CLI (rt_renderer_set_schedule in the C++ adapter); the line it
+    prints comes from rt_stats (what ran: 3 samples x 5 bounces on 3 / 2 / 2 stream lanes), and PNG and ray count stay the oracle's."""
+    from PIL import Image
+    w, h, depth, spp = 96, 64, 5, 3
+    glb = REPO / "assets" / "cube.glb"
+    out, rays = _run(["-w", "-d", depth, "-s", spp, "--width", w, "--height", h, "--quiet", "--schedule", schedule, glb], tmp_path)
+    assert f"launches: {expect}" in out, out
+    exp_u8, exp_rays, _ = _oracle_frame(oracle, glb, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp)
+    assert rays == exp_rays
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "out.png")), exp_u8)
+    p = subprocess.run([str(EXE), "--schedule", "nonsense", str(glb)], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 105

@@ -108,7 +108,7 @@ def test_device_scatter_all_materials(gpu_scenes, oracle, scene_cache):
 
 
 @pytest.mark.parametrize("name,kw,brute", [("triangle", {}, True), ("cube", {}, True), ("cornell", {}, True),
-                                            ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False)])
+                                            ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False), ("voxel", {"detail": 1}, True)])
 @pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH, abi.RT_BVH_LBVH_GPU])
 def test_intersect_batch_equals_oracle(gpu_scenes, oracle, scene_cache, name, kw, brute, bvh):
     """rtcIntersect1 replacement: BVH traversal on the GPU == brute force over all triangles on the CPU,
@@ -173,6 +173,7 @@ CONFIGS = [
     ("cube", {}, 256, 256, 4, 10, False),         # config 2 (512x512x16 at reduced size)
     ("cornell", {}, 160, 160, 8, 10, False),      # config 3 (emissive -> wavefront clamp differs)
     ("atrium", {"detail": 2}, 240, 136, 2, 10, True),  # configs 4/5 geometry class, oracle BVH
+    ("voxel", {"detail": 1}, 200, 112, 3, 10, True),  # the second workload class (the reference's minecraft.glb): axis-aligned unit faces, open sky
     ("cornell", {}, 97, 61, 3, 1, False),         # odd size (partial 8x8 tiles), depth 1
     ("cube", {}, 64, 40, 2, 16, False),           # depth 16 as in config 5
 ]
@@ -675,6 +676,9 @@ FULL_CONFIGS = [
     ("cornell", {}, 1024, 1024, 64, 10, MegakernelRenderer, (40, 100)),      # config 3, other renderer
     ("atrium", {"detail": 4}, 1920, 1080, 64, 10, WavefrontRenderer, (7, 66, 134)),   # config 4 (the bench workload)
     ("atrium", {"detail": 4}, 1920, 1080, 64, 10, MegakernelRenderer, (7, 66, 134)),  # config 4, the bench's headline renderer
+    # the reference's second benchmark scene class (benchmark.py:18, benchmark_avg.csv:20-21: minecraft.glb at depth 10, 128 spp) on the generated voxel terrain
+    ("voxel", {"detail": 4}, 1920, 1080, 128, 10, WavefrontRenderer, (20, 70, 120)),
+    ("voxel", {"detail": 4}, 1920, 1080, 128, 10, MegakernelRenderer, (20, 70, 120)),
 ]
 
 

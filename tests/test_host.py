@@ -57,7 +57,7 @@ def _host_scene(rtlib, sd, bvh=abi.RT_BVH_DEFAULT):
 
 
 @pytest.mark.parametrize("name,kw", [("triangle", {}), ("cube", {}), ("cornell", {}), ("atrium", {"detail": 1}),
-                                      ("atrium", {"detail": 2}), ("empty", {})])
+                                      ("atrium", {"detail": 2}), ("empty", {}), ("voxel", {"detail": 1})])
 @pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH])
 def test_host_bvh_is_structurally_valid(rtlib, scene_cache, name, kw, bvh):
     sd = scene_cache(name, **kw)
@@ -202,6 +202,23 @@ def test_atrium_generator_is_deterministic():
         np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
     assert 10_000 < a.n_triangles < 30_000
     assert a.textures.shape[0] == 9
+
+
+def test_voxel_generator_is_deterministic_and_meshes_only_visible_faces():
+    """The second workload class (the reference's minecraft.glb stand-in): deterministic; every triangle is half of an axis-aligned unit
+    square on the integer grid (block faces between a solid and an empty cell only, so no two triangles coincide)."""
+    a, b = scenes.voxel_scene(1), scenes.voxel_scene(1)
+    for k in ("positions", "normals", "uvs", "indices", "tri_instance", "textures"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    assert 20_000 < a.n_triangles < 40_000 and a.textures.shape[0] == 6
+    kinds = {m.type for m in a.materials}
+    assert kinds == {abi.RT_MAT_DIFFUSE, abi.RT_MAT_METALLIC, abi.RT_MAT_DIELECTRIC}
+    tw = a.world_triangles()
+    assert np.array_equal(tw, np.rint(tw))                       # integer grid
+    ext = tw.max(1) - tw.min(1)
+    assert (np.sort(ext, axis=1) == np.array([0, 1, 1])).all()   # each triangle spans a unit square in one axis plane
+    keys = np.sort(tw.reshape(-1, 9).view([("", tw.dtype)] * 9).ravel())
+    assert len(np.unique(keys)) == a.n_triangles                 # no duplicates
 
 
 def test_builder_stages_keep_the_tree_valid_and_do_not_raise_its_cost(rtlib, scene_cache, monkeypatch):
