@@ -139,9 +139,19 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) {
         best.tri = gidx;
     }
 }
-RT_DEV void tri_test(const TriRec* __restrict__ tr, f3 o, f3 d, Hit& best) {
-    const float4* p4 = reinterpret_cast<const float4*>(tr);
-    tri_test_regs(p4[0], p4[1], *reinterpret_cast<const float2*>(p4 + 2), o, d, best);
+// the packed 40-byte device records are only 8-byte aligned: the loads say so (still one dwordx4 each: gfx950 needs dword alignment only)
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+RT_DEV float4 tri_ld4(const uint8_t* p) {
+    const f4a8 v = *reinterpret_cast<const f4a8*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+RT_DEV float2 tri_ld2(const uint8_t* p) {
+    const f2a8 v = *reinterpret_cast<const f2a8*>(p);
+    return make_float2(v.x, v.y);
+}
+RT_DEV void tri_test(const uint8_t* __restrict__ tr, f3 o, f3 d, Hit& best) {
+    tri_test_regs(tri_ld4(tr), tri_ld4(tr + 16), tri_ld2(tr + 32), o, d, best);
 }
 
 // ---- BVH4 traversal as a resumable per-lane state machine --------------------------------------------
@@ -517,8 +527,8 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         // Unrolled by hand over two register sets (A, B) so that no record is ever copied: the rolled loop moved the prefetched
         // record into the "current" registers every iteration, 25 v_mov_b64 = ~100 of the step's ~900 issue cycles. Every branch
         // condition is wave-uniform (a ballot): the step runs as many tests as the largest leaf among its lanes.
-        const float4* p4 = reinterpret_cast<const float4*>(S.tris + first);
-#define RT_LOAD_TRI(K, A_, B_, C_) A_ = p4[3 * (K)], B_ = p4[3 * (K) + 1], C_ = *reinterpret_cast<const float2*>(p4 + 3 * (K) + 2)
+        const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
+#define RT_LOAD_TRI(K, A_, B_, C_) A_ = tri_ld4(p4 + (K) * kTriBytes), B_ = tri_ld4(p4 + (K) * kTriBytes + 16), C_ = tri_ld2(p4 + (K) * kTriBytes + 32)
         float4 aA, bA, aB, bB;
         float2 cA, cB;
         RT_LOAD_TRI(0, aA, bA, cA);
@@ -541,15 +551,15 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         }
 #undef RT_LOAD_TRI
 #else
-        const float4* p4 = reinterpret_cast<const float4*>(S.tris + first);
-        float4 a = p4[0], b = p4[1];
-        float2 c = *reinterpret_cast<const float2*>(p4 + 2);
+        const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
+        float4 a = tri_ld4(p4), b = tri_ld4(p4 + 16);
+        float2 c = tri_ld2(p4 + 32);
         uint32_t k = 1;
         for (; k < 4u; ++k) {
             if (__ballot(k <= rem) == 0ull) break;
             float4 na = a, nb = b;
             float2 nc = c;
-            if (k <= rem) na = p4[3 * k], nb = p4[3 * k + 1], nc = *reinterpret_cast<const float2*>(p4 + 3 * k + 2);
+            if (k <= rem) na = tri_ld4(p4 + k * kTriBytes), nb = tri_ld4(p4 + k * kTriBytes + 16), nc = tri_ld2(p4 + k * kTriBytes + 32);
             if (k - 1u <= rem) tri_test_regs(a, b, c, T.o, T.d, T.best);
             a = na, b = nb, c = nc;
         }
@@ -572,7 +582,7 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         else trav_pop(T, stack);
 #endif
     } else {
-        tri_test(S.tris + first, T.o, T.d, T.best);
+        tri_test(S.tris + (size_t)first * kTriBytes, T.o, T.d, T.best);
 #if RT_POSTPONE
         const int32_t next = rem ? ~(int32_t)(((first + 1u) << 2) | (rem - 1u)) : kTravDone;
         if (from_pend) T.pend = next;

@@ -172,6 +172,9 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
 #ifndef RT_MEGA_TAIL_UNROLL1
 #define RT_MEGA_TAIL_UNROLL1 0
 #endif
+#ifndef RT_MEGA_MISS_ROUND
+#define RT_MEGA_MISS_ROUND 0 // lanes waiting with a MISS that trigger a round of their own (experiment, measured: DESIGN.md §6); 0 = off
+#endif
 #ifndef RT_MEGA_PRIO
 #define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
                        // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
@@ -311,9 +314,17 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         }
         // TRAVERSE until at least half of the live lanes are waiting for shading
         if (STATS) t_mark = (long long)__builtin_readcyclecounter();
+        bool miss_round = false; // RT_MEGA_MISS_ROUND: this round only ends the paths that missed
+        (void)miss_round;
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
+#if RT_MEGA_MISS_ROUND
+            if ((uint32_t)__popcll(__ballot(waiting && T.best.tri == kNoTri)) >= RT_MEGA_MISS_ROUND) {
+                miss_round = true;
+                break;
+            }
+#endif
             if (STATS) ws.live_lane_steps += n_live;
             refill.stepped();
             (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
@@ -338,6 +349,34 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         __builtin_amdgcn_s_setprio(0);
 #endif
         bool pixel_finished = false;
+#if RT_MEGA_MISS_ROUND
+        // VERDICT r2 item 5, an experiment (default off): a cheap step kind for the paths that END WITHOUT A SCATTER — a ray that missed
+        // adds att * (sky + rad) (shade_hit's miss branch, src/trace_ray.hpp:25-27), its pixel takes its next camera ray or retires —
+        // fired as soon as RT_MEGA_MISS_ROUND lanes wait with a miss, instead of waiting for RT_MEGA_SHADE_PCT of the wave. Per pixel the
+        // operations and their order are those of the full round (the re-packing of an unchanged ray state is the identity).
+        if (miss_round) {
+            if (live && T.cur == kTravDone && T.best.tri == kNoTri) {
+                rays++;
+                const f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2])), rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
+                color = color + att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+                s++;
+                depth = 0;
+                if (s < spp) {
+                    r = camera_ray(cam, x, gy, rng);
+                    trav_begin(T, r.org, ray_dir(r), stack);
+                } else {
+                    live = false, pixel_finished = true;
+                    const float n = (float)spp;
+                    const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
+                    const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
+                    if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                    if (out_u8)
+                        reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+                                                                 ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+                }
+            }
+        } else
+#endif
         if (live && T.cur == kTravDone) {
             f3 res;
             rays++;

@@ -948,7 +948,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
             rc = upload(wide, &s->dev.wnodes, s->device_bytes);
         }
 #endif
-        if (rc == RT_OK) rc = upload(s->hs.tris, &s->dev.tris, s->device_bytes);
+        if (rc == RT_OK) { // the device's triangle records: the host records' ten live dwords at a kTriBytes stride
+            std::vector<uint8_t> packed(s->hs.tris.size() * (size_t)kTriBytes + 16, 0); // + 16: a 16-byte load at the last record's offset 32 stays inside
+            for (size_t i = 0; i < s->hs.tris.size(); ++i) std::memcpy(packed.data() + i * kTriBytes, &s->hs.tris[i], std::min<size_t>(kTriBytes, sizeof(TriRec)));
+            rc = upload(packed, &s->dev.tris, s->device_bytes);
+        }
         if (rc == RT_OK) rc = upload(s->hs.shade, &s->dev.shade, s->device_bytes);
         if (rc == RT_OK) rc = upload(s->hs.inst, &s->dev.inst, s->device_bytes);
         if (rc == RT_OK) rc = upload(s->hs.mats, &s->dev.mats, s->device_bytes);

@@ -67,6 +67,12 @@ struct alignas(16) TriRec {
     uint32_t pad[2];
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+// What the device reads per triangle: the record's ten live dwords, packed (the two padding words were 17 % of the
+// triangle traffic): bytes 0-15 (v0.xyz, e1.x), 16-31 (e1.yz, e2.xy), 32-39 (e2.z, global index) at a 40-byte stride (8-byte aligned).
+#ifndef RT_TRI_BYTES
+#define RT_TRI_BYTES 40
+#endif
+constexpr uint32_t kTriBytes = RT_TRI_BYTES; // 40 (packed) or 48 (the host record as it is)
 
 // ---- per-triangle shading attributes, GLOBAL order: 64 bytes ------------------------------------
 // What trace_ray gathers through index_buffer/normal_buffer/uv_buffer (src/trace_ray.hpp:34-45),
@@ -103,7 +109,7 @@ static_assert(sizeof(MatRec) == 48, "MatRec must be 48 bytes");
 struct SceneDev {
     const BvhNode* nodes;
     const WideNode* wnodes; // RT_WIDE_NODES builds only (else null)
-    const TriRec* tris;
+    const uint8_t* tris; // leaf order, kTriBytes per triangle
     const ShadeRec* shade;
     const InstRec* inst;
     const MatRec* mats;
