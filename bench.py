@@ -98,6 +98,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: CPU rehearsal of the multi-rank path (needs --rehearsal-tiles)")
     ap.add_argument("--rehearsal-tiles", default=None, help="directory with tile_<rank>.npy (rows x W x 4 float32): used INSTEAD of rendering")
     ap.add_argument("--dump-frame", default=None, help="rank 0 writes the last gathered frame here (.npy)")
+    ap.add_argument("--dump-pmc", default=None, help="write the raw counter sums of the live --pmc passes here (JSON; profiles/r03_pmc_bench.json is one)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)  # comma-separated renderers: one untimed frame each, the process rocprofv3 wraps
     return ap.parse_args(argv)
 
@@ -484,13 +485,16 @@ def attach_pmc(out, args):
     if not args.no_live_pmc:
         try:
             c = live_pmc(args, want)
+            if args.dump_pmc:
+                Path(args.dump_pmc).write_text(json.dumps(dict(c, source="bench.py --dump-pmc: rocprofv3 --pmc passes (counters only) of one frame per renderer at the bench "
+                                                                            "configuration; counters summed over the kernel's launches; FETCH_SIZE / WRITE_SIZE in KiB"), indent=1))
             source = f"measured in this run: one more frame per renderer in a child process under rocprofv3 --pmc ({len(PMC_PASSES)} passes, counters only)"
         except Exception as e:  # no rocprofv3 / no counter access here: say so and use the committed profile of the same command
             source = f"live rocprofv3 --pmc unavailable ({str(e)[:160]}); "
     if c is None:
         prof = REPO / "profiles" / "r03_pmc_bench.json"
         if prof.exists():
-            c = json.loads(prof.read_text())
+            c = {k: v for k, v in json.loads(prof.read_text()).items() if isinstance(v, dict)}
             source = (source or "") + "committed profiles/r03_pmc_bench.json (same command: scripts/final_profile.sh)"
     for name in want:
         roof = out["renderers"][name]["roofline"]

@@ -6,6 +6,8 @@ REPO = Path(__file__).resolve().parent.parent
 F, P = REPO / "gpurun_out" / "r03" / "final", REPO / "profiles"
 shutil.copy(F / "bench.json", P / "r03_bench.json")
 shutil.copy(F / "bench_under_rocprof.json", P / "r03_bench_under_rocprof.json")
+if (F / "pmc_bench.json").exists():
+    shutil.copy(F / "pmc_bench.json", P / "r03_pmc_bench.json")
 for name in ("config_table.txt", "tile_scaling.txt", "schedules_64spp.txt"):
     if (F / name).exists():
         shutil.copy(F / name, P / ("r03_" + name))

@@ -7,7 +7,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r03/final; mkdir -p $out
-timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
+timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 --dump-pmc $out/pmc_bench.json > $out/bench.json 2> $out/bench.err
 echo bench done
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-pipelined > $out/bench_under_rocprof.json 2> $out/kt.err
 echo ktrace done

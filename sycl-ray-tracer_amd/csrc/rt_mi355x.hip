@@ -294,12 +294,10 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
 // pixel kept in its lane for all its samples (rt_kernels.h): rt_schedule{finish_depth 0, samples_per_launch 0}.
 bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch == 0 && r->sched.finish_depth == 0 && r->max_depth > 0; }
 // stream lanes (interleaved sub-tiles on HIP streams of their own): 1 for the one-launch schedule, 2 where launches have tails to overlap
-// (three for the split EXTEND + SHADE pipeline of every bounce: 1 / 2 / 3 lanes 4234 / 5126 / 5317 Mrays/s on the atrium at 1080p, 16 spp)
-uint32_t wf_stream_lanes(const rt_renderer* r) {
-    if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u);
-    if (wf_one_launch(r)) return 1u;
-    return r->sched.finish_depth >= r->max_depth && !r->sched.fused_bounce ? 3u : 2u;
-}
+// (the split EXTEND + SHADE pipeline of every bounce on 1 / 2 / 3 lanes: 4166 / 4979 / 5213 Mrays/s on the atrium at 1080p, 64 spp when the host
+// thread does nothing else — but three lanes are 4,038 launches per frame, and in a process that also runs torch (bench.py) the host enqueues
+// them slower than the device consumes them: 333 instead of 208 ms. Two lanes, 2,692 launches, stay ahead of the device: the default.)
+uint32_t wf_stream_lanes(const rt_renderer* r) { return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : 2u); }
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
 bool wf_spread(const rt_renderer* r) {
