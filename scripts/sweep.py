@@ -13,10 +13,12 @@ from rtamd import scenes
 from rtamd.glb_export import export_glb
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-out = Path(sys.argv[2]) if len(sys.argv) > 2 else REPO / "gpurun_out" / "r03" / "sweep"
+out = (Path(sys.argv[2]) if len(sys.argv) > 2 else REPO / "gpurun_out" / "r03" / "sweep").resolve()
 out.mkdir(parents=True, exist_ok=True)
+import tempfile
+tmp = Path(tempfile.mkdtemp(prefix="rt_sweep_"))  # the exported scenes (tens of MB) and out.png stay out of the results directory
 exe = REPO / "sycl-ray-tracer_amd" / "host" / "build" / "raytracer"
-glbs = {"./assets/atrium4.glb": out / "atrium4.glb", "./assets/voxel4.glb": out / "voxel4.glb"}
+glbs = {"./assets/atrium4.glb": tmp / "atrium4.glb", "./assets/voxel4.glb": tmp / "voxel4.glb"}
 if not glbs["./assets/atrium4.glb"].exists():
     export_glb(scenes.atrium_scene(4), glbs["./assets/atrium4.glb"])
 if not glbs["./assets/voxel4.glb"].exists():
@@ -33,7 +35,7 @@ t_all = time.time()
 for (scene, (depth, samples)), renderer in itertools.product(points, renderers):
     tot = [0.0, 0.0, 0]
     for i in range(iters):
-        o = subprocess.check_output([str(exe), renderer, "-d", str(depth), "-s", str(samples), "--quiet", "--out", str(out / "out.png"), str(glbs[scene])], cwd=out).decode()
+        o = subprocess.check_output([str(exe), renderer, "-d", str(depth), "-s", str(samples), "--quiet", "--out", str(tmp / "out.png"), str(glbs[scene])], cwd=tmp).decode()
         if i == 0:
             continue  # benchmark.py:45-46
         rps = float(re.search(r"Rays/sec: (\d+\.\d+)M", o).group(1))
