@@ -39,7 +39,10 @@ enum Op {
     FMA, MUL, ADD_F32, MOV, AND, ADD_U32, LSHR, LSHL, CVT_UBYTE0, CVT_UBYTE2, MIN_F32, MAX3, CMP_E64, CNDMASK_E64, RCP, SQRT, CVT_F32_F16,
     ALT_FMA_CVT, ALT_FMA_FMA_CVT, ALT_MUL_AND,
     CVT_PK_FP8, CVT_PK_BF8, CVT_FP8, CVT_FP8_SDWA, SCALE_PK_FP8, SCALE_PK_BF8, SCALE_PK_FP4, SCALE_FP8, SCALE_PK_F16_FP8, CVT_OFF_I4,
-    FMA_DENORM, AND_FMA_DENORM, AND_CVT_FMA, N_OPS
+    FMA_DENORM, AND_FMA_DENORM, AND_CVT_FMA,
+    // pairing rules: which instruction forms can be the second instruction of a quad-cycle, and what breaks pairing
+    FMA_SGPR, FMA_INLINE, FMA_LITERAL, MUL_LITERAL, ADDU_LITERAL, ALT_CMP_FMA, ALT_SEL_FMA, ALT_MIN_FMA, ALT_MAX3_FMA, ALT_CVT_AND, ALT_CVT_MOV, ALT_CVT_LSHR, ALT_CVT_ADDU,
+    ALT_CVT_FMAC, ALT_CVT_FMA_SGPR, ALT_CVT_FMA_DEP, FMA_SALU, FMA_LDS, ALT_CVT_FMA_SALU, C3S1, C1S3, N_OPS
 };
 static const char* kOpName[N_OPS] = {
     "v_fma_f32", "v_mul_f32", "v_add_f32", "v_mov_b32", "v_and_b32", "v_add_u32", "v_lshrrev_b32", "v_lshlrev_b32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte2",
@@ -48,12 +51,19 @@ static const char* kOpName[N_OPS] = {
     "v_cvt_pk_f32_fp8 (2 values)", "v_cvt_pk_f32_bf8 (2 values)", "v_cvt_f32_fp8 (byte 0)", "v_cvt_f32_fp8_sdwa (byte 2)", "v_cvt_scalef32_pk_f32_fp8 (2 values)",
     "v_cvt_scalef32_pk_f32_bf8 (2 values)", "v_cvt_scalef32_pk_f32_fp4 (2 values)", "v_cvt_scalef32_f32_fp8 (1 value)", "v_cvt_scalef32_pk_f16_fp8 (2 values, packed f16)",
     "v_cvt_off_f32_i4", "v_fma_f32 with a DENORMAL multiplicand (0x0000ab00)", "pair: v_and_b32 (byte in place) + v_fma_f32 on the denormal",
-    "pair: v_cvt_f32_ubyte1 + v_fma_f32 (today's plane decode)"};
+    "pair: v_cvt_f32_ubyte1 + v_fma_f32 (today's plane decode)",
+    "v_fma_f32 with an SGPR multiplicand", "v_fma_f32 with an inline constant (2.0)", "v_fmac_f32 with a 32-bit literal (VOP3 takes none)", "v_mul_f32 with a 32-bit literal", "v_add_u32 with a 32-bit literal",
+    "alternating v_cmp_lt_f32_e64 (sgpr pair) / v_fma_f32", "alternating v_cndmask_b32_e64 / v_fma_f32", "alternating v_min_f32 / v_fma_f32", "alternating v_max3_f32 / v_fma_f32",
+    "alternating v_cvt_f32_ubyte0 / v_and_b32", "alternating v_cvt_f32_ubyte0 / v_mov_b32", "alternating v_cvt_f32_ubyte0 / v_lshrrev_b32", "alternating v_cvt_f32_ubyte0 / v_add_u32",
+    "alternating v_cvt_f32_ubyte0 / v_fmac_f32 (VOP2)", "alternating v_cvt_f32_ubyte0 / v_fma_f32 with an SGPR multiplicand", "alternating v_cvt_f32_ubyte0 / v_fma_f32, the fma reading the cvt's result",
+    "v_fma_f32 with an s_add_u32 after every instruction", "v_fma_f32 with a ds_read_b32 after every 4th instruction", "alternating v_cvt / v_fma with an s_add_u32 after every pair",
+    "3 half-rate (v_cvt) : 1 full-rate (v_fma)", "1 half-rate (v_cvt) : 3 full-rate (v_fma)"};
 // VALU instructions per loop iteration (the asm bodies below)
 static const double kInstrPerIter[N_OPS] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                                            128, 192, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 256, 256};
+                                            128, 192, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 256, 256,
+                                            128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
 // values converted per instruction (conversion ops), for the cycles-per-value column
-static const double kValuesPerInstr[N_OPS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 2, 2, 1, 1, 2, 2, 2, 1, 2, 1, 0, 0, 0};
+static const double kValuesPerInstr[N_OPS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 2, 2, 1, 1, 2, 2, 2, 1, 2, 1, 0, 0, 0};  // (the pairing-rule streams: 0)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define ACC8 "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
@@ -93,6 +103,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define I_SPKF16(n) "v_cvt_scalef32_pk_f16_fp8 %" n ", %10, %8\n\t"
 #define I_OFFI4(n) "v_cvt_off_f32_i4 %" n ", %10\n\t"
 #define I_FMA_DEN(n) "v_fma_f32 %" n ", %10, %8, %" n "\n\t"
+#define I_FMA_S(n) "v_fma_f32 %" n ", %" n ", s22, %9\n\t"
+#define I_FMA_I(n) "v_fma_f32 %" n ", %" n ", 2.0, %9\n\t"
+#define I_FMA_L(n) "v_fmac_f32 %" n ", 0x3f7fbe77, %9\n\t"
+#define I_MUL_L(n) "v_mul_f32 %" n ", 0x3f7fbe77, %" n "\n\t"
+#define I_ADDU_L(n) "v_add_u32 %" n ", 0x12345, %" n "\n\t"
+#define I_FMAC(n) "v_fmac_f32 %" n ", %8, %9\n\t"
+// alternating A (even accumulators) / B (odd accumulators)
+#define ALT(A, B) asm volatile(REP16(A("0") B("1") A("2") B("3") A("4") B("5") A("6") B("7")) : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB)
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k_calib2(uint32_t iters, float seed, unsigned long long* __restrict__ stamps, float* __restrict__ sink) {
@@ -158,6 +176,34 @@ __global__ void __launch_bounds__(1024) k_calib2(uint32_t iters, float seed, uns
                                     "v_cvt_f32_ubyte1 %10, %14\n\t v_fma_f32 %2, %10, %12, %2\n\t v_cvt_f32_ubyte1 %11, %14\n\t v_fma_f32 %3, %11, %12, %3\n\t"))
                          : ACC8, "+v"(t0r), "+v"(t1r), "+v"(t2r), "+v"(t3r) : "v"(b), "v"(c), "v"(u) : CLOB);
         }
+
+        else if (OP == FMA_SGPR) { asm volatile("s_mov_b32 s22, 0x3f7fbe77" ::: "s22"); asm volatile(REP16(EIGHT(I_FMA_S)) : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB, "s22"); }
+        else if (OP == FMA_INLINE) BODY(I_FMA_I);
+        else if (OP == FMA_LITERAL) BODY(I_FMA_L);
+        else if (OP == MUL_LITERAL) BODY(I_MUL_L);
+        else if (OP == ADDU_LITERAL) BODY(I_ADDU_L);
+        else if (OP == ALT_CMP_FMA) ALT(I_CMP, I_FMA);
+        else if (OP == ALT_SEL_FMA) ALT(I_SEL, I_FMA);
+        else if (OP == ALT_MIN_FMA) ALT(I_MIN, I_FMA);
+        else if (OP == ALT_MAX3_FMA) ALT(I_MAX3, I_FMA);
+        else if (OP == ALT_CVT_AND) ALT(I_UB0, I_AND);
+        else if (OP == ALT_CVT_MOV) ALT(I_UB0, I_MOV);
+        else if (OP == ALT_CVT_LSHR) ALT(I_UB0, I_LSHR);
+        else if (OP == ALT_CVT_ADDU) ALT(I_UB0, I_ADDU);
+        else if (OP == ALT_CVT_FMAC) ALT(I_UB0, I_FMAC);
+        else if (OP == ALT_CVT_FMA_SGPR) { asm volatile("s_mov_b32 s22, 0x3f7fbe77" ::: "s22"); asm volatile(REP16(I_UB0("0") I_FMA_S("1") I_UB0("2") I_FMA_S("3") I_UB0("4") I_FMA_S("5") I_UB0("6") I_FMA_S("7")) : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB, "s22"); }
+        else if (OP == ALT_CVT_FMA_DEP) asm volatile(REP16("v_cvt_f32_ubyte0 %0, %10\n\t v_fma_f32 %1, %0, %8, %9\n\t v_cvt_f32_ubyte0 %2, %10\n\t v_fma_f32 %3, %2, %8, %9\n\t"
+                                                           "v_cvt_f32_ubyte0 %4, %10\n\t v_fma_f32 %5, %4, %8, %9\n\t v_cvt_f32_ubyte0 %6, %10\n\t v_fma_f32 %7, %6, %8, %9\n\t") : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB);
+        else if (OP == FMA_SALU) asm volatile(REP16(I_FMA("0") "s_add_u32 s22, s22, 1\n\t" I_FMA("1") "s_add_u32 s22, s22, 1\n\t" I_FMA("2") "s_add_u32 s22, s22, 1\n\t" I_FMA("3") "s_add_u32 s22, s22, 1\n\t"
+                                                    I_FMA("4") "s_add_u32 s22, s22, 1\n\t" I_FMA("5") "s_add_u32 s22, s22, 1\n\t" I_FMA("6") "s_add_u32 s22, s22, 1\n\t" I_FMA("7") "s_add_u32 s22, s22, 1\n\t")
+                                              : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB, "s22", "scc");
+        else if (OP == FMA_LDS) { asm volatile(REP16(I_FMA("0") I_FMA("1") I_FMA("2") I_FMA("3") "ds_read_b32 %11, %12\n\t" I_FMA("4") I_FMA("5") I_FMA("6") I_FMA("7") "ds_read_b32 %11, %12\n\t")
+                                               "s_waitcnt lgkmcnt(0)\n\t" : ACC8 : "v"(b), "v"(c), "v"(u), "v"(t0r), "v"((threadIdx.x & 1023u) * 4u) : CLOB); }
+        else if (OP == ALT_CVT_FMA_SALU) asm volatile(REP16(I_UB0("0") I_FMA("1") "s_add_u32 s22, s22, 1\n\t" I_UB0("2") I_FMA("3") "s_add_u32 s22, s22, 1\n\t"
+                                                            I_UB0("4") I_FMA("5") "s_add_u32 s22, s22, 1\n\t" I_UB0("6") I_FMA("7") "s_add_u32 s22, s22, 1\n\t")
+                                                      : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB, "s22", "scc");
+        else if (OP == C3S1) asm volatile(REP16(I_UB0("0") I_UB0("1") I_UB0("2") I_FMA("3") I_UB0("4") I_UB0("5") I_UB0("6") I_FMA("7")) : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB);
+        else if (OP == C1S3) asm volatile(REP16(I_UB0("0") I_FMA("1") I_FMA("2") I_FMA("3") I_UB0("4") I_FMA("5") I_FMA("6") I_FMA("7")) : ACC8 : "v"(b), "v"(c), "v"(u) : CLOB);
     }
     asm volatile("" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();

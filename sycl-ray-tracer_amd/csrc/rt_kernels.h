@@ -1104,8 +1104,17 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                             __hip_atomic_store(&out_word, ((unsigned long long)b1 << 32) | (unsigned long long)(n_req - c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             break;
                         }
-                        // the block is used up and its last taker is fetching the next one: wait for the new word, then ask again
-                        while ((uint32_t)__hip_atomic_load(&out_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > kOutBlock) __builtin_amdgcn_s_sleep(1);
+                        // the block is used up and its last taker is fetching the next one: wait for the new word, then ask again. The taker depends
+                        // on nobody (one device atomic, one LDS store), so this ends after ~a microsecond; the wait is bounded all the same
+                        // (~seconds): a logic error becomes an error word the host turns into RT_ERR_HIP, not a wave that never leaves.
+                        uint32_t polls = 0;
+                        while ((uint32_t)__hip_atomic_load(&out_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > kOutBlock && ++polls < kRqIdleCap)
+                            __builtin_amdgcn_s_sleep(1);
+                        if (polls >= kRqIdleCap) {
+                            if (fq.error) __hip_atomic_store(fq.error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b0 = 0, c0 = n_req; // (the frame is lost; the slots only have to be addresses inside the queue)
+                            break;
+                        }
                     }
                 }
                 b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0), c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);

@@ -506,7 +506,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                         if (!f0 || !f1) return fail(RT_ERR_HIP, "hipEventCreate failed");
                         HIPCHK(hipEventRecord(f0, ls));
                     }
-                    const FinishRequeue no_fq{nullptr, nullptr, nullptr, 0u};
+                    const FinishRequeue no_fq{nullptr, nullptr, reinterpret_cast<uint32_t*>(L.d_extra + r->spp), 0u}; // only the error word
 #define RT_SHOOT_LAUNCH(ST)                                                                                                                  \
     hipLaunchKernelGGL((k_wf_finish<ST, false, true>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + d,    \
                        cursors + (size_t)s * D + d, L.d_rng, L.d_accum, L.d_extra + s, d, D, 1u, r->rr_start,                                 \
@@ -808,7 +808,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                 if (!L.n_local) continue;
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(L.h_extra.data(), L.d_extra, L.h_extra.size() * 8, hipMemcpyDeviceToHost));
-                if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: the dynamic queue stalled or overflowed (internal error word set)");
+                if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: a queue hand-over stalled or overflowed (internal error word " + std::to_string((unsigned long long)L.h_extra[r->spp]) + ": 1 / 2 dynamic queue, 3 SHOOT's slot allocator)");
                 const bool shoot_frame = r->sched.fused_bounce && std::min(D, r->sched.finish_depth) > 0; // SHOOT queues have holes: counted on the device
                 for (uint32_t s = 0; s < r->spp; ++s) {
                     if (!shoot_frame)
