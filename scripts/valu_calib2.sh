@@ -5,7 +5,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03/calib2
-mkdir -p $O scripts/build
+rm -rf $O; mkdir -p $O scripts/build
 [ -x scripts/build/valu_calib2 ] || hipcc -O2 -std=c++17 --offload-arch=gfx950 scripts/valu_calib2.hip -o scripts/build/valu_calib2
 timeout -k 10 120 scripts/build/valu_calib2 4000 > $O/plain.json
 echo "plain done"

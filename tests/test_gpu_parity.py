@@ -394,6 +394,10 @@ def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, sched):
         tile = r.render_frame(cam)
         f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=2, world=3, strip_rows=8)
         _assert_frames_equal(tile.rgba_f32, tile.rgba_u8, tile.rays, f, b, rays, f"{name} {sched} tile 2/3")
+        r.set_russian_roulette(2)  # the roulette's extra draw sits between shading and the hand-over to the next queue, in every schedule
+        rr = r.render_frame(cam)
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"), rank=2, world=3, strip_rows=8, rr_start=2)
+        _assert_frames_equal(rr.rgba_f32, rr.rgba_u8, rr.rays, f, b, rays, f"{name} {sched} tile 2/3, roulette")
         r.close()
 
 
