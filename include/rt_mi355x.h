@@ -180,10 +180,12 @@ int32_t rt_renderer_local_rows(const rt_renderer* r);
 /* Global row index of local row `local_row` (for de-interleaving a gathered frame). */
 int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row);
 
-/* Per-launch hipEvent timing of the dominant kernel (k_wf_finish — k_wf_extend in the per-bounce schedule —; the megakernel is
- * always timed). Off by default for the wavefront renderer (it adds two event records per launch); also enabled
- * by the environment variable RT_PROFILE_KERNELS=1 at renderer creation. No reference counterpart
- * (the reference's print_elapsed helper is commented out: src/render_wavefront.cpp:129-137). */
+/* Per-launch hipEvent timing of the traversal / shading kernels, each on the stream it is launched on: rt_stats.hot_kernel_ms (the
+ * dominant kernel of the schedule that ran: k_megakernel, k_wf_finish, k_wf_extend or the fused per-bounce kernel) and
+ * rt_stats.kernel_ms[RT_K_*] per family. The megakernel is always timed; off by default for the wavefront renderer (two event records per
+ * launch — three per EXTEND + SHADE pair —, which the per-bounce schedules with their thousands of launches per frame feel); also enabled
+ * by the environment variable RT_PROFILE_KERNELS=1 at renderer creation. No reference counterpart (the reference's print_elapsed helper is
+ * commented out: src/render_wavefront.cpp:129-137). */
 int rt_renderer_set_profiling(rt_renderer* r, int enable);
 
 /* Russian roulette, an EXTENSION: the reference only lists it as a to-do (PLAN.md:23-27) and never implements
@@ -269,7 +271,7 @@ typedef struct rt_stats {
     uint32_t finish_depth;       /* bounces rendered as EXTEND + SHADE launch pairs, min(schedule, max_depth)      */
     uint32_t cost_ordered;       /* 1 = the cost-ordered second launch ran                                          */
     /* with profiling on (rt_renderer_set_profiling): summed hipEvent duration of the launches of the traversal / shading kernel
-     * families (RT_K_MEGAKERNEL, RT_K_WF_EXTEND, RT_K_WF_SHADE, RT_K_WF_FINISH), each on the stream it was launched on; else 0 */
+     * families (RT_K_MEGAKERNEL, RT_K_WF_EXTEND, RT_K_WF_SHADE, RT_K_WF_SHOOT, RT_K_WF_FINISH), each on the stream it was launched on; else 0 */
     double kernel_ms[RT_K_COUNT];
 } rt_stats;
 
