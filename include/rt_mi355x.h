@@ -130,6 +130,9 @@ typedef struct rt_scene_info_t {
     float bounds_hi[3];
     double sah_cost;        /* surface-area-heuristic cost of the tree (diagnostic) */
     uint64_t device_bytes;  /* bytes resident in HBM for this scene */
+    uint32_t n_leaf_records;     /* triangle records in the leaves: n_triangles, plus one per extra leaf a pre-split triangle sits in */
+    uint32_t n_split_triangles;  /* triangles the SAH builder's pre-splitting pass cut into several references (large triangles whose
+                                    boxes enclose much empty space; a result cannot change: closest t, ties to the lowest index) */
 } rt_scene_info_t;
 int rt_scene_info(const rt_scene* scene, rt_scene_info_t* out);
 

@@ -990,6 +990,8 @@ int rt_scene_info(const rt_scene* s, rt_scene_info_t* out) {
     std::memcpy(out->bounds_lo, s->hs.bounds_lo, 12), std::memcpy(out->bounds_hi, s->hs.bounds_hi, 12);
     out->sah_cost = s->hs.sah_cost;
     out->device_bytes = s->device_bytes;
+    out->n_leaf_records = (uint32_t)s->hs.tris.size();
+    out->n_split_triangles = s->hs.n_split_triangles;
     return RT_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <deque>
 #include <functional>
 #include <queue>
@@ -29,12 +30,16 @@ struct GNode { // generic build node
     uint32_t depth = 0;
 };
 
+// The builders work on REFERENCES: (triangle, box). Without pre-splitting there is one reference per triangle and its box is the
+// triangle's; presplit() below replaces large triangles by several references with the boxes of the triangle's clipped pieces.
 struct Builder {
     const std::vector<float>& wv; // 9 per triangle
-    std::vector<uint32_t> order;
+    std::vector<uint32_t> order;   // reference ids, partitioned in place by the builders
     std::vector<GNode> nodes;
-    std::vector<float> cent; // 3 per triangle
-    std::vector<float> tlo, thi; // per-triangle boxes
+    std::vector<float> cent; // 3 per reference
+    std::vector<float> tlo, thi; // per-reference boxes
+    std::vector<uint32_t> ref_tri; // reference -> triangle
+    uint32_t n_split = 0;          // triangles that were split
 
     explicit Builder(const std::vector<float>& w) : wv(w) {
         const size_t n = w.size() / 9;
@@ -42,8 +47,10 @@ struct Builder {
         cent.resize(3 * n);
         tlo.resize(3 * n);
         thi.resize(3 * n);
+        ref_tri.resize(n);
         for (size_t t = 0; t < n; ++t) {
             order[t] = (uint32_t)t;
+            ref_tri[t] = (uint32_t)t;
             for (int a = 0; a < 3; ++a) {
                 float p0 = w[9 * t + a], p1 = w[9 * t + 3 + a], p2 = w[9 * t + 6 + a];
                 tlo[3 * t + a] = std::min(p0, std::min(p1, p2));
@@ -69,6 +76,139 @@ struct Builder {
         }
     }
 };
+
+// ---- spatial pre-splitting of large triangles (early split clipping with a budget) ------------------------------------
+// A triangle that is large against the nodes it ends up in drags their boxes over empty space (a wall made of two triangles, Sponza's
+// floor): every ray through that space pays a node visit and a triangle test for nothing. Its remedy in a top-down builder is the spatial
+// split (Stich et al. 2009); the form built here is the pre-pass of Ernst & Greiner 2007 with a budget, as production builders use it:
+// the references with the FATTEST boxes (most enclosed volume) are cut at the spatial median of their longest axis — the triangle is clipped against the plane
+// (Sutherland-Hodgman, in double), each piece gets the tight box of its polygon — until the budget of extra references is spent or
+// nothing is left above the floor size. The tree is then built over the pieces; a leaf stores the TRIANGLE (each once per leaf).
+// A triangle in several leaves cannot change a result: the closest hit is min t with ties to the lowest triangle index (rule R5),
+// and testing the same triangle twice yields the same t. What it costs: more leaf records; what it buys: tighter boxes.
+struct SplitRef {
+    uint32_t tri;
+    int n;            // polygon vertices
+    double p[10][3];  // a triangle clipped by k axis-aligned planes has at most 3 + k vertices; pieces are cut at most ~7 times
+    float lo[3], hi[3];
+    float key;        // fatness of the box (below): what the heap orders by
+};
+struct SplitRefLess {
+    bool operator()(const SplitRef* a, const SplitRef* b) const { return a->key < b->key; }
+};
+
+// What makes a reference worth splitting is the EMPTY VOLUME its box encloses, not its size: a wall of two axis-aligned triangles has a
+// flat box that drags nothing along (and is cheaper to trace than a tessellated one), a large triangle that runs diagonally through space
+// has a fat one. Key: the geometric mean of the box's three extents (0 for a flat box).
+inline float fatness(const float* lo, const float* hi) {
+    const float dx = std::max(hi[0] - lo[0], 0.0f), dy = std::max(hi[1] - lo[1], 0.0f), dz = std::max(hi[2] - lo[2], 0.0f);
+    return std::cbrt(dx * dy * dz);
+}
+
+inline void poly_box(SplitRef& r, const float* plo, const float* phi) { // tight box of the polygon, rounded outward, inside the parent's
+    for (int a = 0; a < 3; ++a) {
+        double lo = r.p[0][a], hi = r.p[0][a];
+        for (int i = 1; i < r.n; ++i) lo = std::min(lo, r.p[i][a]), hi = std::max(hi, r.p[i][a]);
+        float flo = (float)lo, fhi = (float)hi;
+        if ((double)flo > lo) flo = std::nextafter(flo, -INFINITY);
+        if ((double)fhi < hi) fhi = std::nextafter(fhi, INFINITY);
+        r.lo[a] = std::max(flo, plo[a]), r.hi[a] = std::min(fhi, phi[a]);
+    }
+    r.key = fatness(r.lo, r.hi);
+}
+
+// polygon `in` clipped to the half space (keep_below ? x[axis] <= pos : x[axis] >= pos)
+inline int clip_poly(const double (*in)[3], int n, int axis, double pos, bool keep_below, double (*out)[3]) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const double* a = in[i];
+        const double* b = in[(i + 1) % n];
+        const double da = keep_below ? pos - a[axis] : a[axis] - pos, db = keep_below ? pos - b[axis] : b[axis] - pos;
+        if (da >= 0.0) {
+            if (m < 10) std::memcpy(out[m++], a, sizeof(double) * 3);
+        }
+        if ((da > 0.0 && db < 0.0) || (da < 0.0 && db > 0.0)) {
+            const double t = da / (da - db);
+            if (m < 10) {
+                for (int k = 0; k < 3; ++k) out[m][k] = a[k] + t * (b[k] - a[k]);
+                out[m][axis] = pos;
+                ++m;
+            }
+        }
+    }
+    return m;
+}
+
+// budget: extra references as a fraction of the triangle count; floor_extent: boxes whose fatness is below this are left alone
+void presplit(Builder& b, double budget, float floor_extent) {
+    const size_t T = b.wv.size() / 9;
+    const size_t max_refs = T + (size_t)((double)T * budget);
+    if (T == 0 || max_refs == T) return;
+    std::deque<SplitRef> pool; // stable addresses
+    std::priority_queue<SplitRef*, std::vector<SplitRef*>, SplitRefLess> heap;
+    std::vector<uint8_t> was_split(T, 0);
+    for (size_t t = 0; t < T; ++t) {
+        const float ext = fatness(&b.tlo[3 * t], &b.thi[3 * t]);
+        if (!(ext > floor_extent)) continue;
+        pool.emplace_back();
+        SplitRef& r = pool.back();
+        r.tri = (uint32_t)t, r.n = 3;
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) r.p[v][a] = (double)b.wv[9 * t + 3 * v + a];
+        std::memcpy(r.lo, &b.tlo[3 * t], 12), std::memcpy(r.hi, &b.thi[3 * t], 12);
+        r.key = ext;
+        heap.push(&r);
+    }
+    if (heap.empty()) return;
+    size_t n_refs = T;
+    std::vector<const SplitRef*> done; // pieces that are final
+    while (!heap.empty()) {
+        SplitRef* r = heap.top();
+        heap.pop();
+        if (n_refs >= max_refs || !(r->key > floor_extent) || r->n >= 9) {
+            done.push_back(r);
+            continue;
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (r->hi[a] - r->lo[a] > r->hi[axis] - r->lo[axis]) axis = a;
+        const double pos = 0.5 * ((double)r->lo[axis] + (double)r->hi[axis]);
+        pool.emplace_back();
+        SplitRef& l = pool.back();
+        pool.emplace_back();
+        SplitRef& h = pool.back();
+        l.tri = h.tri = r->tri;
+        l.n = clip_poly(r->p, r->n, axis, pos, true, l.p);
+        h.n = clip_poly(r->p, r->n, axis, pos, false, h.p);
+        if (l.n < 3 || h.n < 3) { // the plane does not cut the polygon (degenerate): leave the piece as it is
+            r->n = 9;             // (never asked again)
+            done.push_back(r);
+            continue;
+        }
+        float llo[3], lhi[3], hlo[3], hhi[3];
+        std::memcpy(llo, r->lo, 12), std::memcpy(lhi, r->hi, 12), std::memcpy(hlo, r->lo, 12), std::memcpy(hhi, r->hi, 12);
+        lhi[axis] = std::nextafter((float)pos, INFINITY), hlo[axis] = std::nextafter((float)pos, -INFINITY);
+        poly_box(l, llo, lhi), poly_box(h, hlo, hhi);
+        was_split[r->tri] = 1;
+        ++n_refs;
+        heap.push(&l), heap.push(&h);
+    }
+    // the reference arrays: unsplit triangles keep their slot; the pieces of split triangles are appended (the first piece takes the slot)
+    std::vector<uint8_t> slot_used(T, 0);
+    for (const SplitRef* r : done) {
+        if (!was_split[r->tri]) continue; // popped but never cut: the triangle's own reference stands
+        size_t id;
+        if (!slot_used[r->tri]) id = r->tri, slot_used[r->tri] = 1;
+        else {
+            id = b.ref_tri.size();
+            b.ref_tri.push_back(r->tri);
+            b.order.push_back((uint32_t)id);
+            b.tlo.resize(3 * (id + 1)), b.thi.resize(3 * (id + 1)), b.cent.resize(3 * (id + 1));
+        }
+        for (int a = 0; a < 3; ++a) b.tlo[3 * id + a] = r->lo[a], b.thi[3 * id + a] = r->hi[a], b.cent[3 * id + a] = 0.5f * (r->lo[a] + r->hi[a]);
+    }
+    for (size_t t = 0; t < T; ++t) b.n_split += was_split[t];
+}
 
 inline float half_area(const float* lo, const float* hi) {
     float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -405,6 +545,42 @@ bool quantise_node(BvhNode& n, int nk, const float (*klo)[3], const float (*khi)
 
 } // namespace
 
+// Which binary nodes become BVH4 nodes: dynamic programme over the binary tree (after Ylitie, Karras, Laine 2017).
+// best[n][k] = least SAH cost of covering subtree n with at most k child slots of its BVH4 parent; a subtree that
+// takes one slot is a leaf or a BVH4 node of its own (area + the best way to hand its 4 slots to its two halves).
+// cut[n][4] = slots a BVH4 node n gives to its LEFT half. best[0][1] / area(root) is the 4-wide tree's surface-area cost.
+static void collapse_dp(const Builder& b, std::vector<std::array<float, 5>>& best, std::vector<std::array<uint8_t, 5>>& cut) {
+    best.assign(b.nodes.size(), {}), cut.assign(b.nodes.size(), {});
+    std::vector<int32_t> post, st{0};
+    while (!st.empty()) { // pre-order, reversed = children before parents
+        const int32_t i = st.back();
+        st.pop_back();
+        post.push_back(i);
+        if (b.nodes[i].left >= 0) st.push_back(b.nodes[i].left), st.push_back(b.nodes[i].right);
+    }
+    for (size_t q = post.size(); q-- > 0;) {
+        const int32_t i = post[q];
+        const GNode& g = b.nodes[i];
+        const float ar = half_area(g.lo, g.hi);
+        if (g.left < 0) {
+            for (int k = 1; k <= 4; ++k) best[i][k] = ar * (float)g.count;
+            continue;
+        }
+        float dist[5];
+        uint8_t dl[5];
+        for (int k = 2; k <= 4; ++k) {
+            dist[k] = std::numeric_limits<float>::infinity(), dl[k] = 1;
+            for (int l = 1; l < k; ++l) {
+                const float c = best[g.left][l] + best[g.right][k - l];
+                if (c < dist[k]) dist[k] = c, dl[k] = (uint8_t)l;
+            }
+        }
+        best[i][1] = ar + dist[4];
+        for (int k = 2; k <= 4; ++k) best[i][k] = std::min(dist[k], best[i][k - 1]);
+        cut[i][4] = dl[4]; // what the node does with its OWN four slots when it is a BVH4 node (best[i][1])
+    }
+}
+
 int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::string& err) {
     if (!d) { err = "null scene description"; return RT_ERR_INVALID; }
     if (d->n_triangles && (!d->positions || !d->normals || !d->uvs || !d->indices || !d->tri_instance)) {
@@ -563,32 +739,75 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         return RT_OK;
     }
 
-    Builder b(hs.wverts);
-    if (bvh_kind == RT_BVH_LBVH || bvh_kind == RT_BVH_LBVH_GPU) build_lbvh(b);
+    std::unique_ptr<Builder> bp(new Builder(hs.wverts));
+    if (bvh_kind == RT_BVH_LBVH || bvh_kind == RT_BVH_LBVH_GPU) build_lbvh(*bp);
     else {
-        build_sah(b, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
+        // pre-splitting of large triangles (SAH builder only): at most 30 % more references, only boxes FATTER (geometric mean of the three
+        // extents) than 1/64 of the scene's largest extent — the finely tessellated bench scene has none and neither have axis-aligned walls
+        // (their trees are unchanged); large triangles that cross space diagonally do. Where it did split, the tree without splits is
+        // built too and the one with the lower surface-area cost is kept (a 116-triangle Cornell box gets worse, a tilted hall 15 % better).
+        // RT_BVH_SPLIT_BUDGET=0 switches it off, RT_BVH_SPLIT_FLOOR=<fraction of the scene extent> moves the floor.
+        double budget = 0.3, floor_frac = 1.0 / 64.0;
+        if (const char* e = std::getenv("RT_BVH_SPLIT_BUDGET")) budget = std::max(0.0, std::min(4.0, std::atof(e)));
+        if (const char* e = std::getenv("RT_BVH_SPLIT_FLOOR")) floor_frac = std::max(1e-4, std::min(1.0, std::atof(e)));
         // one pass over the larger half of the inner nodes: -2.6 % SAH cost, 17.9 -> 17.5 node visits per ray on the
         // atrium (+0.7 % rays/s) for 0.18 s of extra build time; further passes change nothing. RT_BVH_REINSERT=0: off
         int passes = 1;
         double fraction = 0.5;
         if (const char* e = std::getenv("RT_BVH_REINSERT")) passes = std::atoi(e);
         if (const char* e = std::getenv("RT_BVH_REINSERT_FRACTION")) fraction = std::atof(e);
-        if (bvh_kind != RT_BVH_MEDIAN_INTERNAL && passes > 0) optimise_by_reinsertion(b, passes, std::min(1.0, std::max(0.0, fraction)));
+        auto run = [&](Builder& bb, bool split) {
+            if (split && bvh_kind != RT_BVH_MEDIAN_INTERNAL && budget > 0.0) presplit(bb, budget, (float)(floor_frac * (double)ext));
+            build_sah(bb, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
+            if (bvh_kind != RT_BVH_MEDIAN_INTERNAL && passes > 0) optimise_by_reinsertion(bb, passes, std::min(1.0, std::max(0.0, fraction)));
+        };
+        auto wide_cost = [](const Builder& bb) { // surface-area cost of the 4-wide tree the collapse below will make of this binary tree
+            std::vector<std::array<float, 5>> bst;
+            std::vector<std::array<uint8_t, 5>> ct;
+            collapse_dp(bb, bst, ct);
+            return (double)bst[0][1] / std::max(1e-30, (double)half_area(bb.nodes[0].lo, bb.nodes[0].hi));
+        };
+        run(*bp, true);
+        if (bp->n_split > 0) {
+            std::unique_ptr<Builder> plain(new Builder(hs.wverts));
+            run(*plain, false);
+            if (bp->nodes[0].left < 0 || plain->nodes[0].left < 0 || wide_cost(*plain) <= wide_cost(*bp)) bp = std::move(plain);
+        }
     }
+    Builder& b = *bp;
     const GNode& g0 = b.nodes[0];
 
     // Collapse the binary tree into a 4-wide one (repeatedly open the inner child with the largest
     // surface area) and emit it breadth-first: the top levels are contiguous in memory.
     hs.tris.clear();
-    hs.tris.reserve(T);
+    hs.tris.reserve(b.order.size());
     hs.nodes.clear();
     auto leaf_code = [&](const GNode& g, uint32_t depth) -> int32_t {
         uint32_t first = (uint32_t)hs.tris.size();
-        for (uint32_t k = 0; k < g.count; ++k) hs.tris.push_back(gtris[b.order[g.first + k]]);
-        hs.max_leaf_tris = std::max(hs.max_leaf_tris, g.count);
+        uint32_t count = 0;
+        for (uint32_t k = 0; k < g.count; ++k) { // the triangles of the leaf's references, each once; its record keeps the box of its pieces HERE
+            const uint32_t ref = b.order[g.first + k], tri = b.ref_tri[ref];
+            uint32_t at = count;
+            for (uint32_t j = 0; j < count; ++j)
+                if (hs.tris[first + j].global_index == tri) at = j;
+            if (at == count) {
+                hs.tris.push_back(gtris[tri]);
+                for (int a = 0; a < 3; ++a) hs.rec_lo.push_back(b.tlo[3 * ref + a]), hs.rec_hi.push_back(b.thi[3 * ref + a]);
+                ++count;
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    float& lo = hs.rec_lo[3 * (size_t)(first + at) + a];
+                    float& hi = hs.rec_hi[3 * (size_t)(first + at) + a];
+                    lo = std::min(lo, b.tlo[3 * ref + a]), hi = std::max(hi, b.thi[3 * ref + a]);
+                }
+            }
+        }
+        hs.max_leaf_tris = std::max(hs.max_leaf_tris, count);
         hs.max_depth = std::max(hs.max_depth, depth);
-        return ~(int32_t)((first << 2) | (g.count - 1));
+        return ~(int32_t)((first << 2) | (count - 1));
     };
+    hs.rec_lo.clear(), hs.rec_hi.clear();
+    hs.n_split_triangles = b.n_split;
     const double root_area = std::max(1e-30, (double)half_area(g0.lo, g0.hi));
     double cost = 0.0;
     struct Item { int32_t gnode; int32_t slot; uint32_t depth; };
@@ -616,37 +835,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     if (const char* e = std::getenv("RT_BVH_COLLAPSE")) use_dp = std::string(e) != "greedy";
     std::vector<std::array<float, 5>> best;
     std::vector<std::array<uint8_t, 5>> cut;
-    if (use_dp) {
-        best.assign(b.nodes.size(), {}), cut.assign(b.nodes.size(), {});
-        std::vector<int32_t> post, st{0};
-        while (!st.empty()) { // pre-order, reversed = children before parents
-            const int32_t i = st.back();
-            st.pop_back();
-            post.push_back(i);
-            if (b.nodes[i].left >= 0) st.push_back(b.nodes[i].left), st.push_back(b.nodes[i].right);
-        }
-        for (size_t q = post.size(); q-- > 0;) {
-            const int32_t i = post[q];
-            const GNode& g = b.nodes[i];
-            const float ar = half_area(g.lo, g.hi);
-            if (g.left < 0) {
-                for (int k = 1; k <= 4; ++k) best[i][k] = ar * (float)g.count;
-                continue;
-            }
-            float dist[5];
-            uint8_t dl[5];
-            for (int k = 2; k <= 4; ++k) {
-                dist[k] = std::numeric_limits<float>::infinity(), dl[k] = 1;
-                for (int l = 1; l < k; ++l) {
-                    const float c = best[g.left][l] + best[g.right][k - l];
-                    if (c < dist[k]) dist[k] = c, dl[k] = (uint8_t)l;
-                }
-            }
-            best[i][1] = ar + dist[4];
-            for (int k = 2; k <= 4; ++k) best[i][k] = std::min(dist[k], best[i][k - 1]);
-            cut[i][4] = dl[4]; // what the node does with its OWN four slots when it is a BVH4 node (best[i][1])
-        }
-    }
+    if (use_dp) collapse_dp(b, best, cut);
     // children of BVH4 node: expand the recorded decisions (subtree n may use up to k slots)
     std::function<void(int32_t, int, int32_t*, int&)> gather = [&](int32_t n, int k, int32_t* kids, int& nk) {
         const GNode& g = b.nodes[n];
@@ -720,7 +909,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         hs.nodes[it.slot] = out;
     }
     hs.sah_cost = cost;
-    if (hs.tris.size() != T) { err = "internal: triangle count mismatch after build"; return RT_ERR_INVALID; }
+    if (hs.tris.size() < T || hs.tris.size() > b.order.size()) { err = "internal: leaf record count mismatch after build"; return RT_ERR_INVALID; }
     hs.stack_need = need(0);
     if (hs.stack_need + 1 >= (uint32_t)kStackSize) {
         if (bvh_kind != RT_BVH_MEDIAN_INTERNAL) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // balanced fallback
@@ -733,7 +922,10 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
 int check_bvh(const HostScene& hs, std::string& err) {
     const size_t T = hs.wverts.size() / 9;
     if (hs.nodes.empty()) { err = "no root node"; return RT_ERR_INVALID; }
-    std::vector<uint8_t> seen(T, 0);
+    std::vector<uint32_t> seen(T, 0);
+    // pre-split trees (scene_build.cpp: presplit): a triangle may sit in several leaves, each with the box of its pieces there
+    const bool split = hs.rec_lo.size() == 3 * hs.tris.size() && hs.rec_hi.size() == 3 * hs.tris.size() && hs.n_split_triangles > 0;
+    std::vector<std::vector<uint32_t>> pieces(split ? T : 0);
     size_t visited = 0;
     bool ok = true;
     const float inf = std::numeric_limits<float>::infinity();
@@ -772,11 +964,20 @@ int check_bvh(const HostScene& hs, std::string& err) {
             for (uint32_t k = 0; k < count; ++k) {
                 const TriRec& tr = hs.tris[first + k];
                 if (tr.global_index >= T) { fail("leaf triangle has bad global index"); return r; }
-                if (seen[tr.global_index]++) { fail("triangle appears in two leaves"); return r; }
+                for (uint32_t j = 0; j < k; ++j)
+                    if (hs.tris[first + j].global_index == tr.global_index) { fail("triangle twice in one leaf"); return r; }
+                if (seen[tr.global_index]++ && !split) { fail("triangle appears in two leaves"); return r; }
                 const float* w = &hs.wverts[9 * (size_t)tr.global_index];
                 if (tr.v0[0] != w[0] || tr.v0[1] != w[1] || tr.v0[2] != w[2]) { fail("leaf triangle data mismatch"); return r; }
-                for (int v = 0; v < 3; ++v)
-                    for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], w[3 * v + a]), r.hi[a] = std::max(r.hi[a], w[3 * v + a]);
+                if (split) { // the box of the triangle's pieces in THIS leaf (the whole triangle where it was not split)
+                    const float* plo = &hs.rec_lo[3 * (size_t)(first + k)];
+                    const float* phi = &hs.rec_hi[3 * (size_t)(first + k)];
+                    for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], plo[a]), r.hi[a] = std::max(r.hi[a], phi[a]);
+                    pieces[tr.global_index].push_back(first + k);
+                } else {
+                    for (int v = 0; v < 3; ++v)
+                        for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], w[3 * v + a]), r.hi[a] = std::max(r.hi[a], w[3 * v + a]);
+                }
             }
         }
         return r;
@@ -785,6 +986,28 @@ int check_bvh(const HostScene& hs, std::string& err) {
     if (!ok) return RT_ERR_INVALID;
     for (size_t t = 0; t < T; ++t)
         if (!seen[t]) { err = "triangle " + std::to_string(t) + " is in no leaf"; return RT_ERR_INVALID; }
+    if (split) { // the pieces of a split triangle must cover it: every point of a barycentric grid lies in the box of one of its records
+        for (size_t t = 0; t < T; ++t) {
+            if (pieces[t].size() < 2) continue;
+            const float* w = &hs.wverts[9 * t];
+            for (int i = 0; i <= 8; ++i)
+                for (int j = 0; i + j <= 8; ++j) {
+                    const double u = i / 8.0, v = j / 8.0, ww = 1.0 - u - v;
+                    double p[3];
+                    for (int a = 0; a < 3; ++a) p[a] = ww * w[a] + u * w[3 + a] + v * w[6 + a];
+                    bool in = false;
+                    for (uint32_t rec : pieces[t]) {
+                        bool inside = true;
+                        for (int a = 0; a < 3; ++a) {
+                            const double tol = 1e-6 * (std::fabs(p[a]) + 1.0);
+                            inside = inside && p[a] >= (double)hs.rec_lo[3 * (size_t)rec + a] - tol && p[a] <= (double)hs.rec_hi[3 * (size_t)rec + a] + tol;
+                        }
+                        in = in || inside;
+                    }
+                    if (!in) { err = "the pieces of split triangle " + std::to_string(t) + " do not cover it"; return RT_ERR_INVALID; }
+                }
+        }
+    }
     return RT_OK;
 }
 

@@ -18,6 +18,8 @@ struct HostScene {
     std::vector<MatRec> mats;
     std::vector<uint8_t> tex;
     std::vector<float> wverts;    // 9 floats per triangle, global order (diagnostics / checks)
+    std::vector<float> rec_lo, rec_hi; // host SAH builder: per leaf record, the box of the triangle's pieces in that leaf (check_bvh)
+    uint32_t n_split_triangles = 0;    // triangles the SAH builder's pre-splitting pass cut into several references
     uint32_t n_layers = 0;
     float sky[3] = {0.5f, 0.7f, 1.0f};
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};

@@ -85,6 +85,8 @@ class rt_scene_info_t(C.Structure):
         ("bounds_hi", C.c_float * 3),
         ("sah_cost", C.c_double),
         ("device_bytes", C.c_uint64),
+        ("n_leaf_records", C.c_uint32),
+        ("n_split_triangles", C.c_uint32),
     ]
 
 

@@ -712,13 +712,16 @@ def cornell_scene() -> SceneDesc:
     return sb.build()
 
 
-def atrium_scene(detail: int = 4) -> SceneDesc:
+def atrium_scene(detail: int = 4, coarse: bool = False) -> SceneDesc:
     """BASELINE configs 4/5: a deterministic Sponza-like atrium (real Sponza is not available offline).
     Long two-storey hall, colonnades of fluted columns with arches, hanging curtains, open roof,
     8 procedural textures; mostly textured diffuse, two metallic tori, two glass spheres.
-    detail=4 gives ~262k triangles; lower values shrink every tessellation for tests."""
+    detail=4 gives ~262k triangles; lower values shrink every tessellation for tests.
+    coarse=True: floor, walls, gallery slabs and roof are TWO triangles each (the way a modelling tool exports a wall, and the way the real
+    Sponza's large polygons are) instead of regular grids — the case spatial splits in the BVH builder exist for; columns, arches,
+    curtains and centre pieces stay finely tessellated."""
     d = max(1, int(detail))
-    sb = SceneBuilder(f"atrium{d}")
+    sb = SceneBuilder(f"atrium{d}" + ("c" if coarse else ""))
     T = {k: sb.add_texture(texture(*v)) for k, v in {
         "tiles": ("tiles", 11), "bricks": ("bricks", 23), "stone": ("stone", 37), "marble": ("marble", 41),
         "plaster": ("plaster", 53), "wood": ("wood", 67),
@@ -732,27 +735,29 @@ def atrium_scene(detail: int = 4) -> SceneDesc:
     L, Wd, Hs = 14.0, 6.0, 4.0  # half length (x), half width (z), storey height
     q = lambda *a, **k: sb.add_mesh(*mesh_quad(*a, **k))
     g = 8 * d
+    if coarse:
+        g = 0.25  # nx = 4 * g = 1, 2 * g -> 1 (below): one quad per surface
     # ground floor (+y)
-    sb.add_instance(q((-L, 0, Wd), (L, 0, Wd), (L, 0, -Wd), (-L, 0, -Wd), nx=4 * g, ny=2 * g, uv_scale=(14, 6)), M["tiles"])
-    gy = max(1, g // 4)
+    sb.add_instance(q((-L, 0, Wd), (L, 0, Wd), (L, 0, -Wd), (-L, 0, -Wd), nx=max(1, int(4 * g)), ny=max(1, int(2 * g)), uv_scale=(14, 6)), M["tiles"])
+    gy = max(1, int(g // 4))
     for sgn in (-1.0, 1.0):
         za, zb = (Wd - 2.0, Wd) if sgn > 0 else (-Wd, -(Wd - 2.0))  # gallery slab spans z in [za, zb]
         yt, yb = Hs, Hs - 0.25
-        sb.add_instance(q((-L, yt, zb), (L, yt, zb), (L, yt, za), (-L, yt, za), nx=2 * g, ny=gy, uv_scale=(14, 1)), M["marble"])   # top, +y
-        sb.add_instance(q((-L, yb, za), (L, yb, za), (L, yb, zb), (-L, yb, zb), nx=2 * g, ny=gy, uv_scale=(14, 1)), M["plaster"])  # underside, -y
+        sb.add_instance(q((-L, yt, zb), (L, yt, zb), (L, yt, za), (-L, yt, za), nx=max(1, int(2 * g)), ny=gy, uv_scale=(14, 1)), M["marble"])   # top, +y
+        sb.add_instance(q((-L, yb, za), (L, yb, za), (L, yb, zb), (-L, yb, zb), nx=max(1, int(2 * g)), ny=gy, uv_scale=(14, 1)), M["plaster"])  # underside, -y
         if sgn > 0:  # slab front face and side wall, normals facing the hall (-z)
-            sb.add_instance(q((L, yb, za), (-L, yb, za), (-L, yt, za), (L, yt, za), nx=2 * g, ny=1, uv_scale=(14, 0.1)), M["marble"])
-            sb.add_instance(q((L, 0, Wd), (-L, 0, Wd), (-L, 2 * Hs, Wd), (L, 2 * Hs, Wd), nx=4 * g, ny=g, uv_scale=(14, 4)), M["bricks"])
+            sb.add_instance(q((L, yb, za), (-L, yb, za), (-L, yt, za), (L, yt, za), nx=max(1, int(2 * g)), ny=1, uv_scale=(14, 0.1)), M["marble"])
+            sb.add_instance(q((L, 0, Wd), (-L, 0, Wd), (-L, 2 * Hs, Wd), (L, 2 * Hs, Wd), nx=max(1, int(4 * g)), ny=max(1, int(g)), uv_scale=(14, 4)), M["bricks"])
         else:        # normals +z
-            sb.add_instance(q((-L, yb, zb), (L, yb, zb), (L, yt, zb), (-L, yt, zb), nx=2 * g, ny=1, uv_scale=(14, 0.1)), M["marble"])
-            sb.add_instance(q((-L, 0, -Wd), (L, 0, -Wd), (L, 2 * Hs, -Wd), (-L, 2 * Hs, -Wd), nx=4 * g, ny=g, uv_scale=(14, 4)), M["bricks"])
+            sb.add_instance(q((-L, yb, zb), (L, yb, zb), (L, yt, zb), (-L, yt, zb), nx=max(1, int(2 * g)), ny=1, uv_scale=(14, 0.1)), M["marble"])
+            sb.add_instance(q((-L, 0, -Wd), (L, 0, -Wd), (L, 2 * Hs, -Wd), (-L, 2 * Hs, -Wd), nx=max(1, int(4 * g)), ny=max(1, int(g)), uv_scale=(14, 4)), M["bricks"])
     # end walls, normals facing the hall
-    sb.add_instance(q((-L, 0, Wd), (-L, 0, -Wd), (-L, 2 * Hs, -Wd), (-L, 2 * Hs, Wd), nx=2 * g, ny=g, uv_scale=(6, 4)), M["plaster"])
-    sb.add_instance(q((L, 0, -Wd), (L, 0, Wd), (L, 2 * Hs, Wd), (L, 2 * Hs, -Wd), nx=2 * g, ny=g, uv_scale=(6, 4)), M["plaster"])
+    sb.add_instance(q((-L, 0, Wd), (-L, 0, -Wd), (-L, 2 * Hs, -Wd), (-L, 2 * Hs, Wd), nx=max(1, int(2 * g)), ny=max(1, int(g)), uv_scale=(6, 4)), M["plaster"])
+    sb.add_instance(q((L, 0, -Wd), (L, 0, Wd), (L, 2 * Hs, Wd), (L, 2 * Hs, -Wd), nx=max(1, int(2 * g)), ny=max(1, int(g)), uv_scale=(6, 4)), M["plaster"])
     # roof slabs (normals -y) leaving a central skylight slot of width 3
     yr = 2 * Hs
     for za, zb in ((-Wd, -1.5), (1.5, Wd)):
-        sb.add_instance(q((-L, yr, za), (L, yr, za), (L, yr, zb), (-L, yr, zb), nx=2 * g, ny=gy, uv_scale=(14, 2)), M["wood"])
+        sb.add_instance(q((-L, yr, za), (L, yr, za), (L, yr, zb), (-L, yr, zb), nx=max(1, int(2 * g)), ny=gy, uv_scale=(14, 2)), M["wood"])
     # colonnades: one shared column mesh, instanced
     col = sb.add_mesh(*mesh_cylinder(12 * d, 8 * d, radius=0.32, height=Hs - 0.6, flute=0.12, flutes=12))
     cap = sb.add_mesh(*mesh_box((-0.45, 0, -0.45), (0.45, 0.3, 0.45)))
@@ -912,8 +917,31 @@ def voxel_scene(detail: int = 4) -> SceneDesc:
     return sb.build()
 
 
+def rotate_scene(sd: SceneDesc, q, name_suffix="r") -> SceneDesc:
+    """The same scene turned as a whole by the unit quaternion q (every instance transform and normal matrix, the camera): what is
+    axis-aligned in the original runs diagonally through space — large triangles then have fat bounding boxes (the BVH builder's
+    pre-splitting pass exists for those)."""
+    import copy
+    out = copy.copy(sd)
+    R = mat4_from_quat(q)
+    out.transforms = np.stack([mat4_mul(R, m) for m in sd.transforms]).astype(f32)
+    out.normal_mats = np.stack([normal_matrix(m) for m in out.transforms]).astype(f32)
+    r3 = R.reshape(4, 4).T[:3, :3].astype(np.float64)  # column-major storage -> row-major 3x3
+    out.camera = CameraPose(tuple(float(v) for v in r3 @ np.asarray(sd.camera.position, np.float64)),
+                            tuple(float(v) for v in r3 @ np.asarray(sd.camera.direction, np.float64)), sd.camera.focal_length)
+    out.name = sd.name + name_suffix
+    out._keep = []
+    return out
+
+
+def atrium_tilted_scene(detail: int = 4, coarse: bool = True) -> SceneDesc:
+    """The atrium with two-triangle walls, floor, slabs and roof, turned 33 degrees about (0.3, 1, 0.2): no large surface is axis-aligned."""
+    return rotate_scene(atrium_scene(detail, coarse=coarse), quat_axis_angle((0.3, 1.0, 0.2), 0.58))
+
+
 SCENES = {
     "voxel": voxel_scene,
+    "atrium_tilted": atrium_tilted_scene,
     "triangle": triangle_scene,
     "cube": cube_scene,
     "cornell": cornell_scene,

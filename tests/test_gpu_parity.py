@@ -108,7 +108,8 @@ def test_device_scatter_all_materials(gpu_scenes, oracle, scene_cache):
 
 
 @pytest.mark.parametrize("name,kw,brute", [("triangle", {}, True), ("cube", {}, True), ("cornell", {}, True),
-                                            ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False), ("voxel", {"detail": 1}, True)])
+                                            ("atrium", {"detail": 1}, True), ("atrium", {"detail": 2}, False), ("voxel", {"detail": 1}, True),
+                                            ("atrium_tilted", {"detail": 1}, True)])  # the last one: pre-split triangles sit in several leaves
 @pytest.mark.parametrize("bvh", [abi.RT_BVH_LBVH, abi.RT_BVH_SAH, abi.RT_BVH_LBVH_GPU])
 def test_intersect_batch_equals_oracle(gpu_scenes, oracle, scene_cache, name, kw, brute, bvh):
     """rtcIntersect1 replacement: BVH traversal on the GPU == brute force over all triangles on the CPU,
@@ -173,6 +174,7 @@ CONFIGS = [
     ("cube", {}, 256, 256, 4, 10, False),         # config 2 (512x512x16 at reduced size)
     ("cornell", {}, 160, 160, 8, 10, False),      # config 3 (emissive -> wavefront clamp differs)
     ("atrium", {"detail": 2}, 240, 136, 2, 10, True),  # configs 4/5 geometry class, oracle BVH
+    ("atrium_tilted", {"detail": 1}, 200, 112, 3, 10, True),  # large diagonal triangles: the SAH builder pre-splits them (one triangle, several leaves)
     ("voxel", {"detail": 1}, 200, 112, 3, 10, True),  # the second workload class (the reference's minecraft.glb): axis-aligned unit faces, open sky
     ("cornell", {}, 97, 61, 3, 1, False),         # odd size (partial 8x8 tiles), depth 1
     ("cube", {}, 64, 40, 2, 16, False),           # depth 16 as in config 5
@@ -242,6 +244,29 @@ def test_bvh_builder_does_not_change_the_image(gpu_scenes, cls, kind):
     for f in frames[1:]:
         assert frames[0].rays == f.rays
         np.testing.assert_array_equal(frames[0].rgba_f32, f.rgba_f32)
+
+
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_presplit_triangles_do_not_change_the_image(oracle, scene_cache, monkeypatch, cls, kind):
+    """The SAH builder's pre-splitting of large diagonal triangles puts one triangle into several leaves. The closest hit is min t with ties
+    to the lowest triangle index, and the same triangle tested twice gives the same t: frame, unorm8 image and ray count must be those of
+    the tree without splits — and the oracle's."""
+    sd = scene_cache("atrium_tilted", detail=1)
+    w, h, depth, spp = 224, 126, 10, 3
+    cam = Camera.for_scene(sd, (w, h))
+    frames = []
+    for budget in ("0", "0.3", "1.5"):
+        monkeypatch.setenv("RT_BVH_SPLIT_BUDGET", budget)  # read by rt_scene_create
+        gs = Scene(sd, 0, abi.RT_BVH_SAH)
+        info = gs.info()
+        assert (info.n_split_triangles > 0) == (budget != "0") and info.n_leaf_records >= sd.n_triangles
+        r = cls(gs, (w, h), depth, spp)
+        frames.append(r.render_frame(cam))
+        r.close()
+        gs.close()
+    f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp, use_bvh=True)
+    for fr in frames:
+        _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, f, b, rays, "pre-split tree")
 
 
 @pytest.mark.parametrize("cls,kind", KINDS)
