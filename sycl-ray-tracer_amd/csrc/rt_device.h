@@ -620,7 +620,13 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 64u // with whole-leaf steps: leaf lanes that force a leaf step even against an inner majority
 #endif
-    if (ni >= nl && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
+#ifndef RT_LEAF_BIAS_N
+#define RT_LEAF_BIAS_N 3u // the vote's weight: an inner step when ni * N >= nl * D. 1 / 1 is the plain majority of rounds 1-2; 3 / 4 takes a leaf step as soon as
+#define RT_LEAF_BIAS_D 4u // the leaf lanes exceed 3/4 of the inner lanes: a lane parked at a leaf is idle for as many iterations as the vote keeps going
+#endif                    // against it, and a leaf step that comes a little earlier with a few lanes less is cheaper than those idle lanes. Atrium 1080p 64 spp,
+                          // two runs each, megakernel / wavefront Mrays/s: 1/1 7220-7224 / 7185-7195; 5/8 7305-7321 / 7262; 2/3 7330-7338 / 7258-7267; 3/4 7305-7324 /
+                          // 7270-7276; 7/8 7309-7310 / 7254-7265 (8/4, 6/4: 6859, 6988)
+    if (ni * RT_LEAF_BIAS_N >= nl * RT_LEAF_BIAS_D && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
 #if RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
 #else

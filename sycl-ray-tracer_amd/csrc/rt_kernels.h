@@ -164,7 +164,8 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
     }
 };
 #ifndef RT_MEGA_SHADE_PCT
-#define RT_MEGA_SHADE_PCT 80u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %)
+#define RT_MEGA_SHADE_PCT 75u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %; round 3, with the 3/4
+                              // inner / leaf vote: 70 / 75 / 80 / 85 -> 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s megakernel, the wavefront renderer alike)
 #endif
 #ifndef RT_MEGA_TAIL_SHADE_PCT
 #define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
