@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -348,6 +348,11 @@ int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out,
 int rt_probe_scatter(rt_scene* scene, uint32_t material, uint32_t n, const float* dir,
                      const float* normal, const float* uv, const uint32_t* seed, uint8_t* ok,
                      float* out_dir, float* out_att, uint32_t* seed_out);
+
+/* The kernels' short forms of RN(1 / x) and RN(1 / RN(sqrt(x))) (rt_device.h: rcp_rn, inv_sqrt2; glm::normalize as src/trace_ray.hpp and
+ * src/material.hpp use it, the 1 / det of the triangle test) against the IEEE expressions, on ALL 2^32 float bit patterns:
+ * mismatches[0], mismatches[1] = inputs on which they differ. The arithmetic contract requires both to be 0. ~1 s. */
+int rt_probe_rounding(int device, uint64_t* mismatches);
 
 const char* rt_last_error(void);
 int rt_abi_version(void);

@@ -30,9 +30,52 @@ RT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV f3 cross3(f3 a, f3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// ---- correctly rounded 1/x and 1/sqrt(x) in a few fma (round 3) ------------------------------------------------------------
+// The contract wants RN(1 / x) and RN(1 / RN(sqrt(x))) bit for bit. hipcc's IEEE expansions of those are 11 and 28
+// dependent instructions (v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup; the square root with its denormal scaling, two
+// neighbour tests and four selects): a third of a shading round's instructions, in one serial chain. On gfx950
+//     y = v_rcp_f32(x);  y + y * (1 - x * y)                                          (two fma)
+// IS RN(1 / x) for EVERY x whose biased exponent lies in 1..252, either sign, and
+//     r = v_rsq_f32(x);  g = x r, h = r / 2;  e = 1/2 - h g;  g += g e, h += h e;  g + h * (x - g g)        (Goldschmidt + one residual)
+// IS RN(sqrt(x)) for every x with biased exponent 25..254 — checked on ALL 2^32 inputs (scripts/fast_math_verify.hip chose the forms;
+// rt_probe_rounding runs the check on the functions below, in the GPU test suite: tests/test_gpu_parity.py). Outside those ranges
+// (zero, denormals, huge, inf, NaN, negative radicands) a wave-uniform branch takes the compiler's IEEE sequence, so the functions
+// equal the IEEE expressions everywhere; inside, a normalisation costs 14 instructions instead of 28 + 11.
+#ifndef RT_FAST_RN
+#define RT_FAST_RN 1
+#endif
+#ifndef RT_FAST_RN_TRI
+#define RT_FAST_RN_TRI RT_FAST_RN // ... in the triangle test's 1 / det too
+#endif
+RT_DEV float rcp_rn(float x) { // == 1.0f / x
+#if RT_FAST_RN
+    const uint32_t t = __float_as_uint(x) + __float_as_uint(x); // the sign shifted out
+    const bool ok = t - 0x01000000u < 0xFC000000u;              // biased exponent 1 .. 252
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+        const float y = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+    }
+#endif
+    return 1.0f / x;
+}
+RT_DEV float inv_sqrt2(float x) { // == 1.0f / sqrtf(x): two roundings, as glm::normalize / sycl::normalize
+#if RT_FAST_RN
+    const bool ok = __float_as_uint(x) - 0x0C800000u < 0x73000000u; // positive, biased exponent 25 .. 254
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+        const float r = __builtin_amdgcn_rsqf(x);
+        float g = x * r, h = 0.5f * r;
+        const float e = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, e, g), h = __builtin_fmaf(h, e, h);
+        const float s = __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g); // RN(sqrt(x)), exponent 76 .. 191: inside rcp_rn's range
+        const float y = __builtin_amdgcn_rcpf(s);
+        return __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
+    }
+#endif
+    return 1.0f / __builtin_sqrtf(x);
+}
 // glm::normalize / sycl::normalize: v * (1 / sqrt(dot(v,v)))
 RT_DEV f3 normalize3(f3 a) {
-    float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+    const float inv = inv_sqrt2(dot3(a, a));
     return mk3(a.x * inv, a.y * inv, a.z * inv);
 }
 RT_DEV float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
@@ -129,7 +172,11 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) {
     const float un0 = dot3(tv, p), vn0 = dot3(d, q);
     const float un = un0 * sgn, vn = vn0 * sgn;
     if (!(un >= 0.0f && vn >= 0.0f && un + vn <= __builtin_fabsf(det))) return;
+#if RT_FAST_RN_TRI
+    const float inv = rcp_rn(det);
+#else
     const float inv = 1.0f / det;
+#endif
     const float t = dot3(e2, q) * inv;
     if (!(t > kTNear)) return;
     if (t < best.t || (t == best.t && gidx < best.tri)) {
@@ -176,6 +223,9 @@ constexpr int32_t kTravDone = (int32_t)0x80000000;
 #ifndef RT_PP_VOTE
 #define RT_PP_VOTE 0
 #endif
+#ifndef RT_STATS_STALE
+#define RT_STATS_STALE 0
+#endif
 
 struct Trav {
     f3 o, d;              // ray (d unnormalised, as stored)
@@ -187,6 +237,9 @@ struct Trav {
     uint32_t nx, ny, nz; // byte offsets of the ray's NEAR plane words inside a WideNode (x: 0 / 16, y: 32 / 48, z: 64 / 80); far = near ^ 16
 #endif
     uint32_t sp; // LDS byte address of the lane's next free stack entry (TravStack::base = empty); beyond the LDS part it keeps counting
+#if RT_STATS_STALE
+    float cur_t = 0.0f; // entry distance of `cur` as computed when it was pushed / descended into
+#endif
 #if RT_POSTPONE
     int32_t pend = kTravDone; // a postponed leaf (same code as `cur`) or kTravDone: none. Invariant: cur == kTravDone => pend == kTravDone
                               // (a pop from an empty stack hands the postponed leaf back to `cur`)
@@ -212,6 +265,9 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
     T.nx = T.ix < 0.0f ? 16u : 0u, T.ny = T.iy < 0.0f ? 48u : 32u, T.nz = T.iz < 0.0f ? 80u : 64u;
 #endif
     T.cur = 0; // root
+#if RT_STATS_STALE
+    T.cur_t = 0.0f;
+#endif
     T.sp = stack_base(st); // empty stack
 #if RT_POSTPONE
     T.pend = kTravDone;
@@ -234,6 +290,9 @@ struct TravStack {
     uint32_t base;  // LDS byte address of this lane's entry 0
     int32_t* spill; // kStackSize - kLdsStack entries of scratch
     uint32_t pitch; // bytes from one entry of a lane to its next: 4 * threads per block (a power of two)
+#if RT_STATS_STALE
+    float* dstk = nullptr; // kStackSize entry distances (scratch)
+#endif
 };
 RT_DEV uint32_t stack_base(const TravStack& st) { return st.base; }
 RT_DEV lds_i32* lds_at(uint32_t addr) { return (lds_i32*)(size_t)addr; }
@@ -262,10 +321,19 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
         T.sp -= st.pitch;
         const uint32_t e = (T.sp - st.base) / st.pitch;
         T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
+#if RT_STATS_STALE
+        T.cur_t = st.dstk[e];
+#endif
     } else {
         T.cur = kTravDone;
     }
 }
+#if RT_STATS_STALE
+RT_DEV void stk_push_t(const TravStack& st, Trav& T, int32_t v, float t) {
+    st.dstk[(T.sp - st.base) / st.pitch] = t;
+    stk_push(st, T, v);
+}
+#endif
 
 // The first kTopNodes nodes of the breadth-first node array (the top ~5 levels of the BVH4) are staged in
 // LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes of 16 bytes per node (the node's
@@ -330,6 +398,16 @@ RT_DEV uint32_t sel(lmask m, uint32_t a, uint32_t b) {
 }
 RT_DEV int32_t sel(lmask m, int32_t a, int32_t b) { return (int32_t)sel(m, (uint32_t)a, (uint32_t)b); }
 
+// The direction signs of the wave's 64 rays as three lane masks. A ray's signs do not change while it is traversed, so the kernels
+// take them ONCE per traversal phase, in wave-uniform control flow after the shading round that started the rays (trav_signs), and
+// every inner step selects its near / far plane words on these SGPR pairs directly. (Round 3: written as lanes(T.ix < 0.0f) inside the
+// step, the compiler hoisted the compares out of the loop by itself and then rebuilt each mask per step with v_cndmask 0/1 + v_cmp_ne —
+// six half-rate instructions, 24 of the step's ~530 issue cycles, for three masks it already held.) Bits of lanes without a ray are
+// arbitrary and never used.
+struct TravSigns {
+    lmask nx, ny, nz;
+};
+
 // byte k of a word as float (v_cvt_f32_ubyteK)
 RT_DEV float ub0(uint32_t w) { return (float)(w & 0xffu); }
 RT_DEV float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
@@ -350,6 +428,8 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 #ifndef RT_STATS_LEAFWAIT
 #define RT_STATS_LEAFWAIT 0
 #endif
+// RT_STATS_STALE=1 (diagnostic variant, RT_KERNEL_STATS runs): every stack entry carries its entry distance in scratch; the "top nodes" counter counts
+// the inner-step lanes whose node lies beyond best.t by now (a stale pop), "live lanes/step" the same for leaf steps
 #ifndef RT_SIGN_XOR
 #define RT_SIGN_XOR 0
 #endif
@@ -363,7 +443,8 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 #define RT_SORT_CE 4 // 5: full sorting network. 4 (default): nearest and farthest exact, the middle two in either order (-18 issue cycles per
                      // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3: only the nearest exact (+-0)
 #endif
-RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top) {
+RT_DEV TravSigns trav_signs(const Trav& T) { return TravSigns{lanes(T.ix < 0.0f), lanes(T.iy < 0.0f), lanes(T.iz < 0.0f)}; }
+RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg) {
     const float inf = __builtin_huge_valf();
     float k0, k1, k2, k3;
 #if RT_WIDE_NODES
@@ -404,9 +485,15 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + T.cur);
         w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
     }
+#if RT_ORDERED // the grid steps' sign bits hold the node's ordering axis (rt_types.h): |step|, a free source modifier
+    const float ax = __builtin_fabsf(__uint_as_float(w0.w)) * T.ix;
+    const float ay = __builtin_fabsf(__uint_as_float(w2.z)) * T.iy;
+    const float az = __builtin_fabsf(__uint_as_float(w2.w)) * T.iz;
+#else
     const float ax = __uint_as_float(w0.w) * T.ix;
     const float ay = __uint_as_float(w2.z) * T.iy;
     const float az = __uint_as_float(w2.w) * T.iz;
+#endif
     const float bx = __builtin_fmaf(__uint_as_float(w0.x), T.ix, T.ox);
     const float by = __builtin_fmaf(__uint_as_float(w0.y), T.iy, T.oy);
     const float bz = __builtin_fmaf(__uint_as_float(w0.z), T.iz, T.oz);
@@ -420,7 +507,7 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     const uint32_t qny = w1.z ^ dy, qfy = w1.w ^ dy;
     const uint32_t qnz = w2.x ^ dz, qfz = w2.y ^ dz;
 #else
-    const lmask nx = lanes(T.ix < 0.0f), ny = lanes(T.iy < 0.0f), nz = lanes(T.iz < 0.0f);
+    const lmask nx = sg.nx, ny = sg.ny, nz = sg.nz;
     const uint32_t qnx = sel(nx, w1.x, w1.y), qfx = sel(nx, w1.y, w1.x);
     const uint32_t qny = sel(ny, w1.z, w1.w), qfy = sel(ny, w1.w, w1.z);
     const uint32_t qnz = sel(nz, w2.x, w2.y), qfz = sel(nz, w2.y, w2.x);
@@ -458,11 +545,64 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         K = sel(lanes(tn <= tf), inf, tn);                                                               \
     }
 #endif
+#if RT_ORDERED
+#undef RT_CHILD
+#define RT_CHILD(H, CVT)                                                                                  \
+    {                                                                                                    \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
+                                         __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
+                                         __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
+        H = lanes(tn <= tf);                                                                             \
+    }
+    // Children in stored order are front to back for a ray that travels up the node's ordering axis, back to front for one that
+    // travels down it. All the bookkeeping is lane MASKS in scalar registers (s_and / s_or / s_andn2: no vector instruction): which
+    // slot is the first hit in the lane's order (f0..f3), which of the others are pushed, far to near (pA, pB, pC). Vector work:
+    // three selects for the child to descend into, three for the pushed words, one compare for the order.
+    lmask h0, h1, h2, h3;
+    RT_CHILD(h0, ub0)
+    RT_CHILD(h1, ub1)
+    RT_CHILD(h2, ub2)
+    RT_CHILD(h3, ub3)
+#undef RT_CHILD
+    (void)k0, (void)k1, (void)k2, (void)k3, (void)inf;
+    {
+        const uint32_t rvb = (w0.w & __float_as_uint(T.ix)) | (w2.z & __float_as_uint(T.iy)) | (w2.w & __float_as_uint(T.iz));
+        const lmask R = lanes((int32_t)rvb < 0), F = ~R;
+        const lmask any = (h0 | h1) | (h2 | h3);
+        const lmask f0 = h0 & (F | ~(h1 | h2 | h3));
+        const lmask f1 = h1 & ((F & ~h0) | (R & ~(h2 | h3)));
+        const lmask f2 = h2 & ((F & ~(h0 | h1)) | (R & ~h3));
+        const lmask f3 = h3 & (R | ~(h0 | h1 | h2));
+        int32_t nxt = sel(f1, c0, c1);
+        nxt = sel(f2, nxt, c2);
+        nxt = sel(f3, nxt, c3);
+        const int32_t vA = sel(R, c3, c0), vB = sel(R, c2, c1), vC = sel(R, c1, c2);
+        const lmask pA = (F & h3 & ~f3) | (R & h0 & ~f0);
+        const lmask pB = (F & h2 & ~f2) | (R & h1 & ~f1);
+        const lmask pC = (F & h1 & ~f1) | (R & h2 & ~f2);
+        if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) {
+            if (__builtin_amdgcn_inverse_ballot_w64(pA)) stk_push_lds(stack, T, vA);
+            if (__builtin_amdgcn_inverse_ballot_w64(pB)) stk_push_lds(stack, T, vB);
+            if (__builtin_amdgcn_inverse_ballot_w64(pC)) stk_push_lds(stack, T, vC);
+            if (__builtin_amdgcn_inverse_ballot_w64(any)) T.cur = nxt;
+            else trav_pop_lds(T, stack);
+        } else {
+            if (__builtin_amdgcn_inverse_ballot_w64(pA)) stk_push(stack, T, vA);
+            if (__builtin_amdgcn_inverse_ballot_w64(pB)) stk_push(stack, T, vB);
+            if (__builtin_amdgcn_inverse_ballot_w64(pC)) stk_push(stack, T, vC);
+            if (__builtin_amdgcn_inverse_ballot_w64(any)) T.cur = nxt;
+            else trav_pop(T, stack);
+        }
+        return;
+    }
+#else
     RT_CHILD(k0, ub0)
     RT_CHILD(k1, ub1)
     RT_CHILD(k2, ub2)
     RT_CHILD(k3, ub3)
 #undef RT_CHILD
+#endif
 #endif // RT_WIDE_NODES
     // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
     // SGPR pair + four e64 selects on it (18 cycles).
@@ -492,6 +632,14 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     const bool descend = hit0 && !aside;
 #else
     const bool descend = k0 < inf;
+#endif
+#if RT_STATS_STALE
+    if (k3 < inf) stk_push_t(stack, T, c3, k3);
+    if (k2 < inf) stk_push_t(stack, T, c2, k2);
+    if (k1 < inf) stk_push_t(stack, T, c1, k1);
+    if (descend) T.cur = c0, T.cur_t = k0;
+    else trav_pop(T, stack);
+    return;
 #endif
     if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
         if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
@@ -578,8 +726,12 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
             trav_pop(T, stack);
         }
 #else
+#if RT_STATS_STALE
+        trav_pop(T, stack);
+#else
         if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
         else trav_pop(T, stack);
+#endif
 #endif
     } else {
         tri_test(S.tris + (size_t)first * kTriBytes, T.o, T.d, T.best);
@@ -603,7 +755,7 @@ struct WaveStats {
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
 template <bool STATS = false, bool LEAF_BATCH = false>
-RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, WaveStats* ws = nullptr) {
+RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg, WaveStats* ws = nullptr) {
     const bool inner = T.cur >= 0;
 #if RT_POSTPONE
     const bool blocked = (uint32_t)T.cur > 0x80000000u; // at a leaf (negative, not kTravDone)
@@ -627,14 +779,19 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
                           // two runs each, megakernel / wavefront Mrays/s: 1/1 7220-7224 / 7185-7195; 5/8 7305-7321 / 7262; 2/3 7330-7338 / 7258-7267; 3/4 7305-7324 /
                           // 7270-7276; 7/8 7309-7310 / 7254-7265 (8/4, 6/4: 6859, 6988)
     if (ni * RT_LEAF_BIAS_N >= nl * RT_LEAF_BIAS_D && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
-#if RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
+#if RT_STATS_STALE
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur_t > T.best.t));
+#elif RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
 #else
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * (RT_WIDE_NODES ? 128 : 1)));
 #endif
-        if (inner) trav_inner(S, T, stack, top);
+        if (inner) trav_inner(S, T, stack, top, sg);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(__ballot(leaf));
+#if RT_STATS_STALE
+        if (STATS) ws->live_lane_steps += (uint32_t)__popcll(__ballot(leaf && T.cur_t > T.best.t));
+#endif
         if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
     }
 #if RT_POSTPONE
@@ -650,7 +807,8 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 RT_DEV Hit intersect(const SceneDev& S, f3 o, f3 d, const TravStack& stack, const TopTree& top) {
     Trav T;
     trav_begin(T, o, d, stack);
-    while (trav_step_wave(S, T, stack, top)) {}
+    const TravSigns sg = trav_signs(T);
+    while (trav_step_wave(S, T, stack, top, sg)) {}
     return T.best;
 }
 

@@ -278,9 +278,10 @@ __global__ void __launch_bounds__(kTsBlock, RT_TS_OCC) k_megakernel_ts(SceneDev 
             idle_polls = 0;
             if (STATS) c_iters++, c_holding += (unsigned long long)__popcll(__ballot(has));
             const long long t_steps = STATS ? (long long)__builtin_readcyclecounter() : 0;
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+            const TravSigns sg = trav_signs(T);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
             if (STATS) c_step_cycles += (unsigned long long)((long long)__builtin_readcyclecounter() - t_steps);
         }
         if (STATS && lane == 0) {

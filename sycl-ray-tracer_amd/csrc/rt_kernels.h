@@ -45,6 +45,13 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
 }
 
 // LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
+#if RT_STATS_STALE
+#define RT_STALE_DECL float dstk_arr[kStackSize];
+#define RT_STALE_INIT , dstk_arr
+#else
+#define RT_STALE_DECL
+#define RT_STALE_INIT
+#endif
 #if RT_WIDE_NODES
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
     __shared__ u32x4 top_rec[kTopNodes * 8];                                                           \
@@ -64,7 +71,8 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
     __syncthreads();                                                                                   \
     const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
+    RT_STALE_DECL                                                                                      \
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK) RT_STALE_INIT};
 #endif
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
@@ -317,6 +325,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         if (STATS) t_mark = (long long)__builtin_readcyclecounter();
         bool miss_round = false; // RT_MEGA_MISS_ROUND: this round only ends the paths that missed
         (void)miss_round;
+        const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
@@ -326,16 +335,16 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 break;
             }
 #endif
-            if (STATS) ws.live_lane_steps += n_live;
+            if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #if RT_MEGA_TAIL_UNROLL1
             if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
 #endif
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) { // the exit tests are checked every RT_MEGA_UNROLL steps
-                if (STATS) ws.live_lane_steps += n_live;
-                (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+                if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
+                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
@@ -579,14 +588,17 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
     bool exhausted = chunk_pos >= n;
     if (exhausted) return; // (after the workgroup barrier of the LDS fill)
+    TravSigns sg{0ull, 0ull, 0ull};
     for (;;) {
         // start the rays whose data was requested in the previous round: the loads have been in flight
         // for a whole traversal step of the other lanes instead of stalling the wave at the request
+        const bool any_pending = __ballot(pending) != 0ull;
         if (pending) {
             const f3 d = mk3(h2f((uint16_t)pend_a.x), h2f((uint16_t)(pend_a.x >> 16)), h2f((uint16_t)pend_a.y));
             trav_begin(T, mk3(pend_o.x, pend_o.y, pend_o.z), d, stack);
             pending = false;
         }
+        if (any_pending) sg = trav_signs(T); // rays were started: the wave's direction-sign masks, in uniform control flow
         const bool need = T.cur == kTravDone; // finished or empty lane
         const unsigned long long need_m = __ballot(need);
         const uint32_t cnt = (uint32_t)__popcll(need_m);
@@ -626,11 +638,11 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
             continue;
         }
         if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-        (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, &ws);
+        (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, sg, &ws);
 #pragma unroll
         for (int k = 1; k < RT_EXTEND_UNROLL; ++k) { // refill is looked at every RT_EXTEND_UNROLL steps
             if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-            (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, &ws);
+            (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, sg, &ws);
         }
     }
     if (STATS && lane == 0) {
@@ -1027,14 +1039,15 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             continue;
         }
         idle_polls = 0;
+        const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
         for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
             const bool done_trav = live && T.cur == kTravDone;
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, &ws);
+            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
         }
         if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
 #if RT_MEGA_PRIO == 2
@@ -1201,6 +1214,23 @@ __global__ void __launch_bounds__(256) k_probe_half(uint32_t n, const float* __r
     const uint16_t h = f2h(in[i]);
     bits[i] = h;
     out[i] = h2f(h);
+}
+
+// rcp_rn / inv_sqrt2 (rt_device.h) against the IEEE expressions they stand for, on ALL 2^32 bit patterns: bad[0] / bad[1] count the
+// inputs on which they differ (NaN results compare equal). A wave tests 64 consecutive patterns, the guard ranges are multiples of
+// 2^23: every wave is wholly inside or wholly outside the fast path's range.
+__global__ void __launch_bounds__(256) k_probe_rounding(unsigned long long* __restrict__ bad) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nthreads = gridDim.x * 256u;
+    uint32_t b0 = 0, b1 = 0;
+    for (unsigned long long i = tid; i < (1ull << 32); i += nthreads) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float g0 = rcp_rn(x), w0 = 1.0f / x;
+        const float g1 = inv_sqrt2(x), w1 = 1.0f / __builtin_sqrtf(x);
+        if (__float_as_uint(g0) != __float_as_uint(w0) && !(g0 != g0 && w0 != w0)) b0++;
+        if (__float_as_uint(g1) != __float_as_uint(w1) && !(g1 != g1 && w1 != w1)) b1++;
+    }
+    if (b0) atomicAdd(bad + 0, (unsigned long long)b0);
+    if (b1) atomicAdd(bad + 1, (unsigned long long)b1);
 }
 
 __global__ void __launch_bounds__(256) k_probe_scatter(SceneDev S, uint32_t material, uint32_t n,

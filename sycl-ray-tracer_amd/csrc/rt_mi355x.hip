@@ -1502,6 +1502,20 @@ int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out,
     return RT_OK;
 }
 
+int rt_probe_rounding(int device, uint64_t* mismatches) {
+    if (!mismatches) return fail(RT_ERR_INVALID, "bad arguments");
+    int rc = device_ok(device);
+    if (rc != RT_OK) return rc;
+    DevBuf b;
+    HIPCHK(b.alloc(16));
+    HIPCHK(hipMemset(b.p, 0, 16));
+    hipLaunchKernelGGL(k_probe_rounding, dim3(4096), dim3(256), 0, 0, b.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(mismatches, b.p, 16, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_probe_scatter(rt_scene* s, uint32_t material, uint32_t n, const float* dir, const float* normal, const float* uv,
                      const uint32_t* seed, uint8_t* ok, float* out_dir, float* out_att, uint32_t* seed_out) {
     if (!s || !dir || !normal || !uv || !seed || !ok || !out_dir || !out_att || !seed_out || n == 0)

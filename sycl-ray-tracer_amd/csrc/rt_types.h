@@ -25,7 +25,8 @@ struct alignas(64) BvhNode {
     uint32_t q[6]; // qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z
     float scale_y, scale_z;
     int32_t child[4];
-    float scale(int a) const { return a == 0 ? scale_x : (a == 1 ? scale_y : scale_z); }
+    // (RT_ORDERED builds keep a one-hot "ordering axis" flag in the sign bits of the three grid steps: the step itself is |scale|)
+    float scale(int a) const { const float s = a == 0 ? scale_x : (a == 1 ? scale_y : scale_z); return s < 0.0f ? -s : s; }
     void set_scale(int a, float s) { (a == 0 ? scale_x : (a == 1 ? scale_y : scale_z)) = s; }
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
@@ -49,6 +50,14 @@ struct alignas(128) WideNode {
 };
 static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 
+// RT_ORDERED=1 (experiment): the builder stores every node's children in ascending order of their centroids along
+// the axis on which they are spread widest and marks that axis by the sign bit of its grid step; the inner step then visits the
+// children front to back by the SIGN of the ray's direction on that axis (forward or reverse slot order) and needs neither entry
+// distances as sort keys nor a sorting network. Which hit child is taken first can differ from the exact nearest, so node visits
+// may grow: measured in DESIGN.md.
+#ifndef RT_ORDERED
+#define RT_ORDERED 0
+#endif
 #ifndef RT_MAX_LEAF_TRIS
 #define RT_MAX_LEAF_TRIS 4
 #endif

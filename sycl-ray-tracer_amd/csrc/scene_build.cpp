@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -884,6 +885,23 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
                 kids[nk++] = c.right;
             }
         }
+#if RT_ORDERED // children in ascending order of their centroids along the axis on which the centroids are spread widest (rt_types.h)
+        int order_axis = 0;
+        {
+            float spread = -1.0f;
+            for (int a = 0; a < 3; ++a) {
+                float lo = std::numeric_limits<float>::infinity(), hi = -lo;
+                for (int k = 0; k < nk; ++k) {
+                    const float c = b.nodes[kids[k]].lo[a] + b.nodes[kids[k]].hi[a];
+                    lo = std::min(lo, c), hi = std::max(hi, c);
+                }
+                if (hi - lo > spread) spread = hi - lo, order_axis = a;
+            }
+            std::stable_sort(kids, kids + nk, [&](int32_t x, int32_t y) {
+                return b.nodes[x].lo[order_axis] + b.nodes[x].hi[order_axis] < b.nodes[y].lo[order_axis] + b.nodes[y].hi[order_axis];
+            });
+        }
+#endif
         BvhNode out = empty_node();
         Item pending[4];
         int n_pending = 0;
@@ -891,6 +909,9 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         for (int k = 0; k < nk; ++k)
             for (int a = 0; a < 3; ++a) klo[k][a] = b.nodes[kids[k]].lo[a] - hs.pad, khi[k][a] = b.nodes[kids[k]].hi[a] + hs.pad;
         if (!quantise_node(out, nk, klo, khi)) { err = "internal: quantisation failed"; return RT_ERR_INVALID; }
+#if RT_ORDERED
+        out.set_scale(order_axis, -out.scale(order_axis));
+#endif
         for (int k = 0; k < nk; ++k) {
             const GNode& c = b.nodes[kids[k]];
             if (c.left < 0) {
@@ -909,6 +930,16 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         hs.nodes[it.slot] = out;
     }
     hs.sah_cost = cost;
+    if (const char* e = std::getenv("RT_BVH_VERBOSE")) { // diagnostic: leaves by size
+        if (e[0] == '1') {
+            size_t by[5] = {0, 0, 0, 0, 0};
+            for (const BvhNode& n : hs.nodes)
+                for (int k = 0; k < 4; ++k)
+                    if (n.child[k] < 0 && n.child[k] != kChildEmpty) by[(((uint32_t)~n.child[k]) & 3u) + 1u]++;
+            std::fprintf(stderr, "[rt bvh] %zu nodes, leaves with 1 / 2 / 3 / 4 triangles: %zu / %zu / %zu / %zu, %zu records for %u triangles (%u split)\n", hs.nodes.size(),
+                         by[1], by[2], by[3], by[4], hs.tris.size(), T, hs.n_split_triangles);
+        }
+    }
     if (hs.tris.size() < T || hs.tris.size() > b.order.size()) { err = "internal: leaf record count mismatch after build"; return RT_ERR_INVALID; }
     hs.stack_need = need(0);
     if (hs.stack_need + 1 >= (uint32_t)kStackSize) {

@@ -174,6 +174,7 @@ PROTOTYPES = {
                                    _P(C.c_float), _P(C.c_uint32), _P(C.c_uint8), _P(C.c_float),
                                    _P(C.c_float), _P(C.c_uint32)]),
     "rt_last_error": (C.c_char_p, []),
+    "rt_probe_rounding": (C.c_int, [C.c_int, _P(C.c_uint64)]),
     "rt_abi_version": (C.c_int, []),
     "rt_device_count": (C.c_int, []),
 }

@@ -19,7 +19,9 @@ BUILD = REPO / "sycl-ray-tracer_amd" / "csrc" / "build"
 #   ts      : k_megakernel_ts, seven traversal waves and one shading wave per workgroup exchanging pixel slots through LDS queues
 #             (rt_kernel_ts.h; compiled into this library only, selected with RT_MEGA_TS=1): a pixel's rays are traced and shaded one
 #             after the other by DIFFERENT lanes, so frame, unorm8 image and ray count must still equal the oracle's MegakernelRenderer
-VARIANTS = {"postpone": (BUILD / "librt_exp_postpone.so", {}), "ts": (BUILD / "librt_exp_ts.so", {"RT_MEGA_TS": "1"})}
+#   ordered : RT_ORDERED=1, children visited in stored (builder-sorted) order by the ray's direction sign instead of sorted by entry distance
+VARIANTS = {"postpone": (BUILD / "librt_exp_postpone.so", {}), "ts": (BUILD / "librt_exp_ts.so", {"RT_MEGA_TS": "1"}),
+            "ordered": (BUILD / "librt_exp_ordered.so", {})}
 # beyond the two base frames: tiny frames (fewer pixels than one workgroup has slots), frames that are not a multiple of the 8x8 tiles,
 # an odd tile of a split, Russian roulette, max_depth 1 — megakernel only
 EXTRA = [("cube", {}, (1, 1), 5, 2, None, 0), ("cube", {}, (37, 21), 1, 3, None, 0), ("cornell", {}, (333, 187), 6, 2, (1, 3), 0),

@@ -63,6 +63,15 @@ def test_device_xorshift(rtlib, gpu, oracle):
         assert st.value == est
 
 
+def test_short_reciprocal_and_inverse_square_root_are_ieee_on_every_input(rtlib, gpu):
+    """rcp_rn / inv_sqrt2 (rt_device.h): v_rcp / v_rsq + a few fma in place of the compiler's IEEE division and square root, inside
+    guard ranges found by exhaustive search. The contract (R1) needs RN(1 / x) and RN(1 / RN(sqrt(x))) exactly: compared on the device
+    with the IEEE expressions on all 2^32 bit patterns, no input may differ."""
+    bad = (C.c_uint64 * 2)()
+    abi.check(rtlib.rt_probe_rounding(gpu, bad))
+    assert (bad[0], bad[1]) == (0, 0)
+
+
 def test_device_half_roundtrip(rtlib, gpu, oracle):
     rng = np.random.default_rng(3)
     x = rng.integers(0, 2 ** 32, 300000, dtype=np.uint64).astype(np.uint32).view(np.float32)
