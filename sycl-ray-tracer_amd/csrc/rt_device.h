@@ -479,12 +479,23 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 #undef RT_CHILD
 #else
     u32x4 w0, w1, w2, chw;
+#if RT_NODE_OFFSETS // T.cur = byte offset of the node (rt_types.h)
+    if (T.cur < top.count * 64) { // top of the tree: LDS, 16 bytes per node and plane
+        const uint32_t o = (uint32_t)T.cur >> 2;
+        w0 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w0 + o), w1 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w1 + o);
+        w2 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w2 + o), chw = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.ch + o);
+    } else {
+        const u32x4* np = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)T.cur);
+        w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
+    }
+#else
     if (T.cur < top.count) { // top of the tree: LDS
         w0 = top.w0[T.cur], w1 = top.w1[T.cur], w2 = top.w2[T.cur], chw = top.ch[T.cur];
     } else {
         const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + T.cur);
         w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
     }
+#endif
 #if RT_ORDERED // the grid steps' sign bits hold the node's ordering axis (rt_types.h): |step|, a free source modifier
     const float ax = __builtin_fabsf(__uint_as_float(w0.w)) * T.ix;
     const float ay = __builtin_fabsf(__uint_as_float(w2.z)) * T.iy;
@@ -784,7 +795,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #elif RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
 #else
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * (RT_WIDE_NODES ? 128 : 1)));
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * (RT_WIDE_NODES ? 128 : RT_NODE_OFFSETS ? 64 : 1)));
 #endif
         if (inner) trav_inner(S, T, stack, top, sg);
     } else {
@@ -911,9 +922,9 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
-    const uint32_t inst_id = __float_as_uint(s3.w);
-    const InstRec& inst = S.inst[inst_id];
-    const MatRec& mat = S.mats[inst.material];
+    const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
+    const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
+    const MatRec& mat = S.mats[S.packed_mat ? (iw >> kPackedInstBits) : inst.material];
     const float bx = h.u, by = h.v;
     const float w = (1.0f - bx) - by;
     const float tu = (w * uv0x + bx * uv1x) + by * uv2x;

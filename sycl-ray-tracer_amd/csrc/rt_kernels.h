@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
             const uint32_t tri = __float_as_uint(hits[i].w);
             kind = 0u;
             if (tri != kNoTri) {
-                const uint32_t inst_id = S.shade[tri].instance;
+                const uint32_t inst_id = S.shade[tri].instance & (S.packed_mat ? kPackedInstMask : ~0u);
                 kind = 1u + (S.mats[S.inst[inst_id].material].type & 3u);
             }
         }

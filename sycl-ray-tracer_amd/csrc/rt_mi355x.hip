@@ -926,7 +926,21 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
     s->device = device;
     if (device >= 0) {
         rc = device_ok(device);
+#if RT_NODE_OFFSETS && !RT_WIDE_NODES
+        if (rc == RT_OK) {
+            if (s->hs.nodes.size() > (size_t)(0x7FFFFFFF / 64)) { // (a tree of 33 M nodes: ~130 M triangles)
+                rt_scene_destroy(s);
+                return fail(RT_ERR_INVALID, "BVH too large for 32-bit node offsets");
+            }
+            std::vector<BvhNode> dn(s->hs.nodes);
+            for (BvhNode& n : dn)
+                for (int k = 0; k < 4; ++k)
+                    if (n.child[k] >= 0) n.child[k] *= 64;
+            rc = upload(dn, &s->dev.nodes, s->device_bytes);
+        }
+#else
         if (rc == RT_OK) rc = upload(s->hs.nodes, &s->dev.nodes, s->device_bytes);
+#endif
 #if RT_WIDE_NODES
         if (rc == RT_OK) {
             std::vector<WideNode> wide(s->hs.nodes.size());
@@ -962,6 +976,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
         s->dev.n_nodes = (uint32_t)s->hs.nodes.size();
         s->dev.n_tris = (uint32_t)(s->hs.wverts.size() / 9);
         std::memcpy(s->dev.sky, s->hs.sky, 12);
+        s->dev.packed_mat = s->hs.packed_mat ? 1u : 0u;
         for (int a = 0; a < 3; ++a) {
             const float ext = s->hs.bounds_hi[a] - s->hs.bounds_lo[a];
             s->dev.cell_lo[a] = s->hs.bounds_lo[a];

@@ -58,6 +58,12 @@ static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 #ifndef RT_ORDERED
 #define RT_ORDERED 0
 #endif
+// RT_NODE_OFFSETS=1 (default): in the DEVICE copy of the node array a child word >= 0 is the child node's BYTE offset (index * 64), so that
+// the inner step addresses the node with no arithmetic of its own — a 32-bit offset on the scalar base for global memory (the index form
+// cost a 64-bit shift and a 64-bit add per step), one right shift for the LDS copy of the tree's top. The host array keeps indices.
+#ifndef RT_NODE_OFFSETS
+#define RT_NODE_OFFSETS 1
+#endif
 #ifndef RT_MAX_LEAF_TRIS
 #define RT_MAX_LEAF_TRIS 4
 #endif
@@ -86,6 +92,10 @@ constexpr uint32_t kTriBytes = RT_TRI_BYTES; // 40 (packed) or 48 (the host reco
 // ---- per-triangle shading attributes, GLOBAL order: 64 bytes ------------------------------------
 // What trace_ray gathers through index_buffer/normal_buffer/uv_buffer (src/trace_ray.hpp:34-45),
 // pre-gathered per triangle so a hit costs one aligned 64-byte fetch instead of a dependent chain.
+// `instance`: the instance index — and, in scenes with at most 2^20 instances and 2^12 materials (SceneDev::packed_mat), the instance's
+// material index in bits 20..31 as well: shading then fetches the material record side by side with the instance record instead of
+// after it (one hop less in the chain shade record -> instance -> material -> texel).
+constexpr uint32_t kPackedInstBits = 20, kPackedInstMask = (1u << kPackedInstBits) - 1u;
 struct alignas(64) ShadeRec {
     float n0[3], n1[3], n2[3];
     float uv0[2], uv1[2], uv2[2];
@@ -127,6 +137,7 @@ struct SceneDev {
     uint32_t n_tris;
     float sky[3];
     float cell_lo[3], cell_scale[3]; // ray re-ordering (f-3): cell = (origin - cell_lo) * cell_scale, 0..4 per axis over the scene's bounds
+    uint32_t packed_mat;             // 1: ShadeRec::instance carries the material index in bits 20..31
 };
 
 // == Camera POD (src/camera.hpp:65-72)

@@ -617,6 +617,10 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     hs.sky[0] = d->sky[0], hs.sky[1] = d->sky[1], hs.sky[2] = d->sky[2];
     hs.n_layers = d->n_layers;
     if (d->n_layers) hs.tex.assign(d->textures, d->textures + (size_t)d->n_layers * 512u * 512u * 4u);
+#ifndef RT_PACKED_MAT
+#define RT_PACKED_MAT 1 // (0: A/B builds)
+#endif
+    hs.packed_mat = RT_PACKED_MAT && d->n_instances <= (1u << kPackedInstBits) && d->n_materials <= (1u << (32u - kPackedInstBits));
     hs.inst.resize(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         std::memcpy(hs.inst[i].normal_mat, d->instances[i].normal_mat, sizeof(float) * 9);
@@ -661,7 +665,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         std::memcpy(s.n2, d->normals + 3 * i2, 12);
         std::memcpy(s.uv0, d->uvs + 2 * i0, 8), std::memcpy(s.uv1, d->uvs + 2 * i1, 8);
         std::memcpy(s.uv2, d->uvs + 2 * i2, 8);
-        s.instance = ii;
+        s.instance = hs.packed_mat ? (ii | (hs.inst[ii].material << kPackedInstBits)) : ii;
     }
     for (size_t i = 0; i < hs.wverts.size(); ++i) {
         if (!std::isfinite(hs.wverts[i])) { err = "non-finite world-space vertex"; return RT_ERR_INVALID; }

@@ -21,6 +21,7 @@ struct HostScene {
     std::vector<float> rec_lo, rec_hi; // host SAH builder: per leaf record, the box of the triangle's pieces in that leaf (check_bvh)
     uint32_t n_split_triangles = 0;    // triangles the SAH builder's pre-splitting pass cut into several references
     uint32_t n_layers = 0;
+    bool packed_mat = false;      // ShadeRec::instance = instance | material << 20 (rt_types.h)
     float sky[3] = {0.5f, 0.7f, 1.0f};
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
     float pad = 0.0f;             // absolute box padding used by the builder
