@@ -160,7 +160,24 @@ struct Hit {
 // Moller-Trumbore on the precomputed (v0, e1, e2); barycentrics in Embree's convention
 // P = (1-u-v) v0 + u v1 + v v2. Edge tests on the sign-corrected numerators; one division per
 // accepted candidate. Minimum t wins, equal t -> lowest global index (order independent).
-RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) { // the record's 10 live dwords
+// RT_SHADE_PREFETCH=1 (round 3, an experiment, measured and OFF): the renderers' traversal touches the shading record of every NEW
+// closest hit the moment the triangle test accepts it — one dword of the 64-byte record, loaded into a per-wave LDS sink that nobody
+// reads (global_load_lds: no VGPR is written, so nothing can be clobbered when the data arrives) — so that the line is on its way into
+// the L2 while the ray works through the rest of its stack and then waits for its wave's shading round. The idea came from measuring
+// how much the round's fetch latency weighs: the same fetches with the non-temporal hint (RT_SHADE_NT) cost 25 % of the frame. The
+// prefetch costs 6.4 % instead of gaining (143.7 -> 153.4 ms, bit-exact): vector memory loads return IN ORDER, so the next inner
+// step's s_waitcnt for its node fetch also waits for the prefetch issued before it — a miss into the Infinity Cache that the traversal
+// never had on its critical path before. gfx950 has no fire-and-forget vector prefetch (scalar loads need uniform addresses).
+#ifndef RT_SHADE_PREFETCH
+#define RT_SHADE_PREFETCH 0
+#endif
+RT_DEV void shade_prefetch(const void* shade_base, uint32_t tri, uint32_t lds_sink) {
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    __builtin_amdgcn_global_load_lds((gvoid*)(reinterpret_cast<const char*>(shade_base) + (uint32_t)(tri << 6)), (lvoid*)(size_t)lds_sink, 4, 0, 0);
+}
+template <bool PF = false>
+RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best, const void* shade_base = nullptr, uint32_t lds_sink = 0) { // the record's 10 live dwords
     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     const uint32_t gidx = __float_as_uint(c.y);
     const f3 p = cross3(d, e2);
@@ -184,6 +201,7 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) {
         best.u = un0 * inv;
         best.v = vn0 * inv;
         best.tri = gidx;
+        if (PF && RT_SHADE_PREFETCH) shade_prefetch(shade_base, gidx, lds_sink);
     }
 }
 // the packed 40-byte device records are only 8-byte aligned: the loads say so (still one dwordx4 each: gfx950 needs dword alignment only)
@@ -290,6 +308,7 @@ struct TravStack {
     uint32_t base;  // LDS byte address of this lane's entry 0
     int32_t* spill; // kStackSize - kLdsStack entries of scratch
     uint32_t pitch; // bytes from one entry of a lane to its next: 4 * threads per block (a power of two)
+    uint32_t pf_sink; // wave-uniform LDS byte address of this wave's 256-byte prefetch sink (shade_prefetch)
 #if RT_STATS_STALE
     float* dstk = nullptr; // kStackSize entry distances (scratch)
 #endif
@@ -672,7 +691,7 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 // the wave's vote, so every extra leaf step costs it several iterations; the next record is fetched while the current
 // one is tested (two in flight, 24 VGPRs), the loop bound is the wave's largest leaf (uniform branch). Measured on the
 // megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
-template <bool BATCH>
+template <bool BATCH, bool PF = false>
 RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
 #if RT_POSTPONE
     const bool from_pend = T.pend != kTravDone; // the postponed leaf first: it is the older (usually nearer) one
@@ -696,16 +715,16 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
             aB = aA, bB = bA, cB = cA; // lanes without a triangle 1 re-read nothing: defined values, never tested
             if (rem >= 1u) RT_LOAD_TRI(1, aB, bB, cB);
         }
-        tri_test_regs(aA, bA, cA, T.o, T.d, T.best);
+        tri_test_regs<PF>(aA, bA, cA, T.o, T.d, T.best, S.shade, stack.pf_sink);
         if (more1) {
             const bool more2 = __ballot(rem >= 2u) != 0ull;
             if (more2 && rem >= 2u) RT_LOAD_TRI(2, aA, bA, cA);
-            if (rem >= 1u) tri_test_regs(aB, bB, cB, T.o, T.d, T.best);
+            if (rem >= 1u) tri_test_regs<PF>(aB, bB, cB, T.o, T.d, T.best, S.shade, stack.pf_sink);
             if (more2) {
                 const bool more3 = __ballot(rem >= 3u) != 0ull;
                 if (more3 && rem >= 3u) RT_LOAD_TRI(3, aB, bB, cB);
-                if (rem >= 2u) tri_test_regs(aA, bA, cA, T.o, T.d, T.best);
-                if (more3 && rem >= 3u) tri_test_regs(aB, bB, cB, T.o, T.d, T.best);
+                if (rem >= 2u) tri_test_regs<PF>(aA, bA, cA, T.o, T.d, T.best, S.shade, stack.pf_sink);
+                if (more3 && rem >= 3u) tri_test_regs<PF>(aB, bB, cB, T.o, T.d, T.best, S.shade, stack.pf_sink);
             }
         }
 #undef RT_LOAD_TRI
@@ -719,10 +738,10 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
             float4 na = a, nb = b;
             float2 nc = c;
             if (k <= rem) na = tri_ld4(p4 + k * kTriBytes), nb = tri_ld4(p4 + k * kTriBytes + 16), nc = tri_ld2(p4 + k * kTriBytes + 32);
-            if (k - 1u <= rem) tri_test_regs(a, b, c, T.o, T.d, T.best);
+            if (k - 1u <= rem) tri_test_regs<PF>(a, b, c, T.o, T.d, T.best, S.shade, stack.pf_sink);
             a = na, b = nb, c = nc;
         }
-        if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
+        if (rem + 1u >= k) tri_test_regs<PF>(a, b, c, T.o, T.d, T.best, S.shade, stack.pf_sink); // triangle k-1, still untested where it exists
 #endif
 #if RT_POSTPONE
         // the lane's own leaf is done: pop. The postponed one is done: if the lane also sits at a leaf, that one is set aside now
@@ -765,7 +784,7 @@ struct WaveStats {
 };
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
-template <bool STATS = false, bool LEAF_BATCH = false>
+template <bool STATS = false, bool LEAF_BATCH = false, bool PF = false>
 RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg, WaveStats* ws = nullptr) {
     const bool inner = T.cur >= 0;
 #if RT_POSTPONE
@@ -803,7 +822,7 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
 #if RT_STATS_STALE
         if (STATS) ws->live_lane_steps += (uint32_t)__popcll(__ballot(leaf && T.cur_t > T.best.t));
 #endif
-        if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
+        if (leaf) trav_leaf<LEAF_BATCH, PF>(S, T, stack);
     }
 #if RT_POSTPONE
     { // the stack ran dry while a leaf is set aside: it becomes the lane's current node (keeps cur == kTravDone <=> traversal complete)
@@ -857,6 +876,9 @@ RT_DEV float unorm8_to_float(uint32_t b) {
     return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
 }
 
+#ifndef RT_SHADE_NT
+#define RT_SHADE_NT 0 // experiment: shading records and texels fetched with the non-temporal hint (used once per hit; 18 + 9 MB that compete with nodes and triangles for the 4 MiB L2s)
+#endif
 // Texture::sample (src/material.hpp:45-53): constant colour, or nearest / repeat / normalised
 // fetch from layer tex_layer of the 512x512 RGBA8 array (sampler: src/render_wavefront.cpp:193-197)
 RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
@@ -867,8 +889,13 @@ RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
     int iv = (int)__builtin_floorf(fv * 512.0f);
     iu = iu < 0 ? 0 : (iu > 511 ? 511 : iu);
     iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
+#if RT_SHADE_NT
+    const uint32_t texel = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(
+        S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u));
+#else
     const uint32_t texel = *reinterpret_cast<const uint32_t*>(
         S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u);
+#endif
     return mk3(unorm8_to_float(texel & 0xffu), unorm8_to_float((texel >> 8) & 0xffu), unorm8_to_float((texel >> 16) & 0xffu));
 }
 
@@ -918,8 +945,17 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
         result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
         return true;
     }
+#if RT_SHADE_NT
+    const u32x4* sp = reinterpret_cast<const u32x4*>(S.shade + h.tri);
+    const u32x4 r0 = __builtin_nontemporal_load(sp), r1 = __builtin_nontemporal_load(sp + 1), r2 = __builtin_nontemporal_load(sp + 2), r3 = __builtin_nontemporal_load(sp + 3);
+    const float4 s0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+    const float4 s1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+    const float4 s2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+    const float4 s3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
+#else
     const float4* sp = reinterpret_cast<const float4*>(S.shade + h.tri);
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+#endif
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)

@@ -45,6 +45,13 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
 }
 
 // LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
+#if RT_SHADE_PREFETCH // the per-wave LDS sink of shade_prefetch (rt_device.h): 256 bytes per wave
+#define RT_PF_DECL(BLOCK) __shared__ uint32_t pf_sink_lds[(BLOCK)];
+#define RT_PF_SINK (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lds_i32*)((int32_t*)pf_sink_lds + (threadIdx.x & ~63u)))
+#else
+#define RT_PF_DECL(BLOCK)
+#define RT_PF_SINK 0u
+#endif
 #if RT_STATS_STALE
 #define RT_STALE_DECL float dstk_arr[kStackSize];
 #define RT_STALE_INIT , dstk_arr
@@ -61,7 +68,7 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     top_tree_fill(S, top_rec, top_count);                                                              \
     __syncthreads();                                                                                   \
     const TopTree top{(uint32_t)(size_t)(lds_u32x4*)top_rec, top_count * 128};                         \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK), 0u};
 #else
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
     __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_w2[kTopNodes], top_ch[kTopNodes];       \
@@ -72,7 +79,8 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     __syncthreads();                                                                                   \
     const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
     RT_STALE_DECL                                                                                      \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK) RT_STALE_INIT};
+    RT_PF_DECL(BLOCK)                                                                                  \
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK), RT_PF_SINK RT_STALE_INIT};
 #endif
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
@@ -337,14 +345,14 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
 #endif
             if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
 #if RT_MEGA_TAIL_UNROLL1
             if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
 #endif
 #pragma unroll
             for (int k = 1; k < RT_MEGA_UNROLL; ++k) { // the exit tests are checked every RT_MEGA_UNROLL steps
                 if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
-                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+                (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
@@ -1045,9 +1053,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
             if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
         }
         if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
 #if RT_MEGA_PRIO == 2
