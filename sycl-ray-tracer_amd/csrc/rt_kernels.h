@@ -592,6 +592,8 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
     // wave-uniform chunk state. The first chunk is static (chunk index = block index) so that the
     // thousands of waves of a launch do not all start with an atomic on the same word; later chunks
     // come from the cursor, offset by the static ones.
+    // (With 8 waves per SIMD asked for by every launch, the static chunks already cover a 1 M-ray queue: SHOOT's guided claims — rt_mi355x.hip,
+    // wf_shoot_tail — were tried here too and LOSE a third, 5.2 -> 3.4 Grays/s on two stream lanes: they turn static chunks into cursor claims.)
     uint32_t chunk_pos = wave_id * kExtendChunk;
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
     bool exhausted = chunk_pos >= n;
@@ -923,8 +925,21 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     uint32_t id = 0, rng = 0, depth = 0, rays = 0;
     uint32_t samples_left = 0;  // samples of this lane's pixel still to render in this launch, the current one included
     bool first_counted = false; // the current path's first ray is a queue entry (counted by the host as the queue's length)
-    uint32_t chunk_pos = wave_id * chunk_slots; // first chunk static, later ones from the cursor (as EXTEND)
-    uint32_t chunk_end = chunk_pos + chunk_slots < n ? chunk_pos + chunk_slots : n;
+    // SHOOT, experiment (RT_WF_SHOOT_TAIL=1, bit 31 of chunk_slots): near the queue's end a wave claims a SHARE of what is left instead of a
+    // whole chunk — a wave that starts a private 128-slot chunk when the cursor reaches the end is two ray generations behind the others
+    const bool tail_guided = LIMIT && (chunk_slots >> 31) != 0u;
+    const uint32_t static_pct = (chunk_slots >> 16) & 0x7Fu; // guided: the share of the queue handed out statically, in per cent
+    chunk_slots &= 0xFFFFu;
+    // the static first chunk. Guided: static_pct of the queue in equal parts, whole generations of 64 slots, at least one
+    uint32_t first_slots = chunk_slots;
+    if (tail_guided) {
+        const uint32_t per_wave = (uint32_t)(((unsigned long long)n * static_pct / 100u) / (n_waves ? n_waves : 1u));
+        first_slots = per_wave < 64u ? 64u : (per_wave & ~63u);
+    }
+    uint32_t seen = n_waves * first_slots;                                    // the cursor as this wave last saw it (+ the static chunks)
+    const uint32_t inv_waves = tail_guided ? 0x10000u / (n_waves ? n_waves : 1u) + 1u : 0u; // share = left * inv_waves >> 16 (rounded up a little)
+    uint32_t chunk_pos = wave_id * first_slots; // first chunk static, later ones from the cursor (as EXTEND)
+    uint32_t chunk_end = chunk_pos + first_slots < n ? chunk_pos + first_slots : n;
     bool exhausted = chunk_pos >= n; // the sample-0 queue has no chunk left for this wave
     auto leave = [&]() { // SHOOT: the workgroup's last wave to exit marks the unused tail of the workgroup's output block
         if (!LIMIT) return;
@@ -975,10 +990,17 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                         // through when the other waves have left. Single paths are short: there a chunk per atomic is right.
                         // (SHOOT with guided chunk sizes — a share of what is left, 512 ... 64 slots, to save cursor atomics — was measured slower:
                         // 58.6 -> 66.2 ms at 16 spp; a wave that starts a long private chunk near the end sets the launch's tail.)
-                        const uint32_t w = !REQ && n_samples > 1u ? cnt : chunk_slots;
+                        uint32_t w = !REQ && n_samples > 1u ? cnt : chunk_slots;
+                        if (tail_guided) {
+                            const uint32_t left = n > seen ? n - seen : 0u;
+                            const uint32_t share = (uint32_t)(((unsigned long long)left * inv_waves) >> 16);
+                            const uint32_t least = cnt > 16u ? cnt : 16u;
+                            if (share < w) w = share > least ? share : least;
+                        }
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(cursor, w);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * chunk_slots;
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * first_slots;
+                        seen = base + w;
                         if (base >= n) {
                             exhausted = true;
                         } else {

@@ -204,6 +204,14 @@ struct rt_renderer {
     //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
     rt_schedule sched{RT_WF_FINISH_DEPTH_DEFAULT, RT_WF_SAMPLES_PER_LAUNCH_DEFAULT, 0u, -1, 0u, 0u, -1, 0u, 0u};
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC, tuning)
+    // SHOOT's input claims (round 3). A device atomic on the queue cursor serialises (~6 ns each, more under contention): with 128-slot
+    // claims a 2 M-ray launch made 16 k of them, and smaller claims were far worse (64 slots: 4.7 -> 3.8 Grays/s, 32: 2.3). Now 85 % of
+    // the queue is handed out STATICALLY in equal parts (whole 64-slot generations per wave) and only the rest goes through the cursor,
+    // in claims of a share of what is left (at most 256 slots, at least the wave's idle lanes or 16) so that no wave starts a long
+    // private chunk when the others are about to leave: 2 / 3 stream lanes 5.20 / 5.28 -> 5.66 / 5.75 Grays/s at 16 spp.
+    uint32_t wf_shoot_chunk = 0; // queue slots per cursor claim at most; 0 = 256 guided, 128 (64 on small tiles) unguided (RT_WF_SHOOT_CHUNK)
+    bool wf_shoot_tail = true;   // guided claims (RT_WF_SHOOT_TAIL=0: a fixed chunk per claim, the first one static, as EXTEND)
+    uint32_t wf_shoot_static_pct = 85; // guided: the share of the queue handed out statically (RT_WF_SHOOT_STATIC_PCT)
     hipGraphExec_t graph_exec = nullptr;
     float* graph_f32 = nullptr; // outputs the captured graph writes
     uint8_t* graph_u8 = nullptr;
@@ -297,7 +305,11 @@ bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch ==
 // (the split EXTEND + SHADE pipeline of every bounce on 1 / 2 / 3 lanes: 4166 / 4979 / 5213 Mrays/s on the atrium at 1080p, 64 spp when the host
 // thread does nothing else — but three lanes are 4,038 launches per frame, and in a process that also runs torch (bench.py) the host enqueues
 // them slower than the device consumes them: 333 instead of 208 ms. Two lanes, 2,692 launches, stay ahead of the device: the default.)
-uint32_t wf_stream_lanes(const rt_renderer* r) { return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : 2u); }
+// (stream lanes by default: 1 for the one-launch schedule, 3 for one fused kernel per bounce — 2,118 launches per 64-spp frame, each lane's
+//  launches asking for 2 of the 6 wave slots per SIMD; 4 lanes leave each launch one wave per SIMD and halve the rate — 2 otherwise)
+uint32_t wf_stream_lanes(const rt_renderer* r) {
+    return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : r->sched.fused_bounce ? 3u : 2u);
+}
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
 bool wf_spread(const rt_renderer* r) {
@@ -497,9 +509,11 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 if (r->sched.fused_bounce) { // SHOOT: intersect + shade + compact in ONE launch per bounce (k_wf_finish<.., LIMIT> with a limit of one bounce)
                     constexpr uint32_t fin_wpb = RT_MEGA_BLOCK / 64;
                     const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
-                    const uint32_t chunk_slots = L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk;
-                    const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + chunk_slots - 1u) / chunk_slots, fin_cap));
+                    const uint32_t chunk_slots = r->wf_shoot_chunk ? r->wf_shoot_chunk : r->wf_shoot_tail ? 256u : (L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk);
+                    const uint32_t first_slots = r->wf_shoot_tail ? 64u : chunk_slots; // (guided: the kernel sizes the static part from the queue's length; 64 = at least)
+                    const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + first_slots - 1u) / first_slots, fin_cap));
                     const uint32_t fin_grid = (fin_waves + fin_wpb - 1u) / fin_wpb;
+                    const uint32_t chunk_arg = chunk_slots | (r->wf_shoot_tail ? 0x80000000u | (r->wf_shoot_static_pct << 16) : 0u);
                     hipEvent_t f0 = nullptr, f1 = nullptr;
                     if (r->profile_kernels) {
                         f0 = pool_event(L.ev_pool, ne[k]), f1 = pool_event(L.ev_pool, ne[k] + 1);
@@ -510,7 +524,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
 #define RT_SHOOT_LAUNCH(ST)                                                                                                                  \
     hipLaunchKernelGGL((k_wf_finish<ST, false, true>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + d,    \
                        cursors + (size_t)s * D + d, L.d_rng, L.d_accum, L.d_extra + s, d, D, 1u, r->rr_start,                                 \
-                       ST ? r->d_stats : (unsigned long long*)nullptr, no_fq, chunk_slots, (uint8_t*)nullptr, L.q[buf[k] ^ 1], counts + d + 1, 1u, 1u)
+                       ST ? r->d_stats : (unsigned long long*)nullptr, no_fq, chunk_arg, (uint8_t*)nullptr, L.q[buf[k] ^ 1], counts + d + 1, 1u, 1u)
                     if (r->d_stats) RT_SHOOT_LAUNCH(true);
                     else RT_SHOOT_LAUNCH(false);
 #undef RT_SHOOT_LAUNCH
@@ -1097,6 +1111,9 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if ((std::getenv("RT_WF_REQUEUE") || std::getenv("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
         if (const char* e = std::getenv("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
+        if (const char* e = std::getenv("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
+        if (const char* e = std::getenv("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
+        if (const char* e = std::getenv("RT_WF_SHOOT_STATIC_PCT")) r->wf_shoot_static_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_REORDER")) sc.reorder = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_FUSED_BOUNCE")) sc.fused_bounce = e[0] == '1';

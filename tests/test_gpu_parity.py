@@ -414,7 +414,8 @@ def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, sched):
         back = r.get_schedule()
         assert all(getattr(back, k) == int(v) for k, v in sched.items())
         got = r.render_frame(cam)
-        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else 2)  # automatic: 1 for the one-launch schedule, else 2
+        # automatic: 1 for the one-launch schedule, 3 for one fused kernel per bounce, else 2
+        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else 3 if sched.get("fused_bounce") else 2)
         assert got.stream_lanes == lanes and got.finish_depth == min(sched.get("finish_depth", 0), depth)
         assert got.kernels["wf_init"] == got.kernels["wf_resolve"] == lanes
         fused = bool(sched.get("fused_bounce"))  # one SHOOT launch per bounce instead of the EXTEND + SHADE pair
