@@ -881,6 +881,25 @@ RT_DEV float unorm8_to_float(uint32_t b) {
 #endif
 // Texture::sample (src/material.hpp:45-53): constant colour, or nearest / repeat / normalised
 // fetch from layer tex_layer of the 512x512 RGBA8 array (sampler: src/render_wavefront.cpp:193-197)
+// ... in two halves, so that shading can issue the texel fetch (a miss into the Infinity Cache more often than not: 9 MB of texels,
+// nearest, used once) as soon as the hit's uv is known and interpolate / normalise / draw while it is in flight, instead of reaching
+// it at the end of Material::scatter's branch with nothing left to do but wait (round 3; RT_EARLY_TEXEL=0 restores the late fetch)
+#ifndef RT_EARLY_TEXEL
+#define RT_EARLY_TEXEL 1
+#endif
+RT_DEV bool albedo_is_texture(const MatRec& m) { return (m.type == RT_MAT_DIFFUSE || m.type == RT_MAT_METALLIC) && m.tex_kind != RT_TEX_COLOR; }
+RT_DEV uint32_t albedo_fetch(const SceneDev& S, const MatRec& m, float u, float v) { // caller: albedo_is_texture(m)
+    float fu = u - __builtin_floorf(u);
+    float fv = v - __builtin_floorf(v);
+    int iu = (int)__builtin_floorf(fu * 512.0f);
+    int iv = (int)__builtin_floorf(fv * 512.0f);
+    iu = iu < 0 ? 0 : (iu > 511 ? 511 : iu);
+    iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
+    return *reinterpret_cast<const uint32_t*>(S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u);
+}
+RT_DEV f3 albedo_decode(uint32_t texel) {
+    return mk3(unorm8_to_float(texel & 0xffu), unorm8_to_float((texel >> 8) & 0xffu), unorm8_to_float((texel >> 16) & 0xffu));
+}
 RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
     if (m.tex_kind == RT_TEX_COLOR) return mk3(m.color[0], m.color[1], m.color[2]);
     float fu = u - __builtin_floorf(u);
@@ -901,8 +920,10 @@ RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
 
 // Material::scatter (src/material.hpp:211-224) with the three material bodies (:72-86, :98-110,
 // :127-156). Returns false when the path is absorbed.
+// (PRE: `texel` was fetched by the caller with albedo_fetch where albedo_is_texture(m))
+template <bool PRE = false>
 RT_DEV bool scatter(const SceneDev& S, const MatRec& m, uint32_t& rng, f3 dir, f3 normal, float u, float v,
-                    f3& out_dir, f3& out_att) {
+                    f3& out_dir, f3& out_att, uint32_t texel = 0) {
     // Diffuse (:72-86) and metallic (:98-110) share everything that is expensive — the three RNG draws + normalisation of
     // random_unit_vector and the albedo fetch — so they run as ONE instruction stream with the per-material operands selected:
     // a shading round of ~48 lanes nearly always holds both kinds, and two separate branches would execute that code twice.
@@ -915,7 +936,8 @@ RT_DEV bool scatter(const SceneDev& S, const MatRec& m, uint32_t& rng, f3 dir, f
         const f3 offs = diffuse ? unit : m.roughness * unit;                // diffuse: normal + unit; metallic: reflected + roughness * unit
         out_dir = base + offs;
         if (diffuse && near_zero3(dir)) out_dir = normal;                   // tests the incoming direction, as the reference does
-        out_att = albedo(S, m, u, v);
+        if (PRE) out_att = m.tex_kind == RT_TEX_COLOR ? mk3(m.color[0], m.color[1], m.color[2]) : albedo_decode(texel);
+        else out_att = albedo(S, m, u, v);
         return diffuse ? true : dot3(out_dir, normal) > 0.0f;
     }
     if (m.type == RT_MAT_DIELECTRIC) {
@@ -959,22 +981,65 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
+#ifndef RT_SHADE_RECORDS_UPFRONT
+#define RT_SHADE_RECORDS_UPFRONT 2 // bit 0: the instance record, bit 1: the material record
+#endif
+#if RT_SHADE_RECORDS_UPFRONT
+    // The instance and material records are read WHOLE, here, as three 16-byte words each, and live in registers for the rest of the
+    // round: one memory round trip after the shading record's, then one for the texel. Read field by field at their uses (round 2) they
+    // became five more dependent fetches, each stuck behind a branch — the texture kind, the layer, the normal matrix after the first
+    // normalisation, the emission, the roughness — and a shading round is made of waiting: ~21,000 wave cycles against ~600 instructions.
+#if RT_SHADE_RECORDS_UPFRONT & 1
+    InstRec inst;
+    {
+        const u32x4* ip = reinterpret_cast<const u32x4*>(S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw));
+        const u32x4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
+        inst.normal_mat[0] = __uint_as_float(i0.x), inst.normal_mat[1] = __uint_as_float(i0.y), inst.normal_mat[2] = __uint_as_float(i0.z);
+        inst.normal_mat[3] = __uint_as_float(i0.w), inst.normal_mat[4] = __uint_as_float(i1.x), inst.normal_mat[5] = __uint_as_float(i1.y);
+        inst.normal_mat[6] = __uint_as_float(i1.z), inst.normal_mat[7] = __uint_as_float(i1.w), inst.normal_mat[8] = __uint_as_float(i2.x);
+        inst.material = i2.y;
+    }
+#else
+    const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
+#endif
+#if RT_SHADE_RECORDS_UPFRONT & 2
+    MatRec mat;
+    {
+        const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + (S.packed_mat ? (iw >> kPackedInstBits) : inst.material));
+        const u32x4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        mat.type = m0.x, mat.tex_kind = m0.y, mat.color[0] = __uint_as_float(m0.z), mat.color[1] = __uint_as_float(m0.w);
+        mat.color[2] = __uint_as_float(m1.x), mat.tex_layer = m1.y, mat.emissive[0] = __uint_as_float(m1.z), mat.emissive[1] = __uint_as_float(m1.w);
+        mat.emissive[2] = __uint_as_float(m2.x), mat.roughness = __uint_as_float(m2.y), mat.ior = __uint_as_float(m2.z);
+    }
+#else
+    const MatRec& mat = S.mats[S.packed_mat ? (iw >> kPackedInstBits) : inst.material];
+#endif
+#else
     const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
     const MatRec& mat = S.mats[S.packed_mat ? (iw >> kPackedInstBits) : inst.material];
+#endif
     const float bx = h.u, by = h.v;
     const float w = (1.0f - bx) - by;
     const float tu = (w * uv0x + bx * uv1x) + by * uv2x;
     const float tv = (w * uv0y + bx * uv1y) + by * uv2y;
+#if RT_EARLY_TEXEL
+    uint32_t texel = 0;
+    if (albedo_is_texture(mat)) texel = albedo_fetch(S, mat, tu, tv); // in flight during everything below
+#endif
+    const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237 (here: its operands die early)
+    rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
     const f3 vn = normalize3((w * n0 + bx * n1) + by * n2);
     const float* nm = inst.normal_mat;
     const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
                      (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
     const f3 normal = normalize3(g);
     const f3 d = normalize3(dir);
-    const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237
-    rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
     f3 sdir, satt;
+#if RT_EARLY_TEXEL
+    if (scatter<true>(S, mat, rng, d, normal, tu, tv, sdir, satt, texel)) {
+#else
     if (scatter(S, mat, rng, d, normal, tu, tv, sdir, satt)) {
+#endif
         org = mk3(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
         dir = sdir;
         att = att * satt;

@@ -224,8 +224,15 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     const int lane = (int)(threadIdx.x & 63u);
     uint32_t* pixel_cursor = reinterpret_cast<uint32_t*>(ray_counter + 1);
     int x = 0, ly = 0, gy = 0;
-    uint32_t rays = 0, rng = 0, s = 0, depth = 0;
-    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t rng = 0, s = 0, depth = 0;
+    unsigned long long wave_rays = 0; // rays traced by this wave (wave-uniform: a scalar pair, no lane register, no reduction at the end)
+    // the pixel's colour sum lives in LDS (three planes, one slot per lane): touched once per PATH, it would otherwise hold three of the 80
+    // vector registers through every traversal step of a kernel that spills
+    __shared__ float color_lds[3 * RT_MEGA_BLOCK];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    lds_f32* const color_r = (lds_f32*)color_lds + threadIdx.x;
+    lds_f32* const color_g = color_r + RT_MEGA_BLOCK;
+    lds_f32* const color_b = color_g + RT_MEGA_BLOCK;
     RayState r{};
     Trav T;
     RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
@@ -262,7 +269,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         gy = tile_global_row(tile, ly);
         if (x < cam.width && ly < tile.local_rows && gy < cam.height) {
             rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
-            color = mk3(0.0f, 0.0f, 0.0f);
+            *color_r = 0.0f, *color_g = 0.0f, *color_b = 0.0f;
             s = 0, depth = 0;
             r = camera_ray(cam, x, gy, rng);
             trav_begin(T, r.org, ray_dir(r), stack);
@@ -367,16 +374,18 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         __builtin_amdgcn_s_setprio(0);
 #endif
         bool pixel_finished = false;
+        if (!miss_round) wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
 #if RT_MEGA_MISS_ROUND
         // VERDICT r2 item 5, an experiment (default off): a cheap step kind for the paths that END WITHOUT A SCATTER — a ray that missed
         // adds att * (sky + rad) (shade_hit's miss branch, src/trace_ray.hpp:25-27), its pixel takes its next camera ray or retires —
         // fired as soon as RT_MEGA_MISS_ROUND lanes wait with a miss, instead of waiting for RT_MEGA_SHADE_PCT of the wave. Per pixel the
         // operations and their order are those of the full round (the re-packing of an unchanged ray state is the identity).
         if (miss_round) {
+            wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && T.best.tri == kNoTri));
             if (live && T.cur == kTravDone && T.best.tri == kNoTri) {
-                rays++;
                 const f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2])), rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-                color = color + att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+                const f3 add = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+                *color_r = *color_r + add.x, *color_g = *color_g + add.y, *color_b = *color_b + add.z;
                 s++;
                 depth = 0;
                 if (s < spp) {
@@ -385,7 +394,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 } else {
                     live = false, pixel_finished = true;
                     const float n = (float)spp;
-                    const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
+                    const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
                     const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
                     if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
                     if (out_u8)
@@ -397,13 +406,12 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
 #endif
         if (live && T.cur == kTravDone) {
             f3 res;
-            rays++;
             const bool done = shade_bounce(S, rng, r, T.best, res);
             depth++;
             bool killed = false;
             if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
             if (done || killed || depth == max_depth) {
-                if (done) color = color + res; // paths that outlive max_depth add (0,0,0)
+                if (done) *color_r = *color_r + res.x, *color_g = *color_g + res.y, *color_b = *color_b + res.z; // paths that outlive max_depth add (0,0,0)
                 s++;
                 depth = 0;
                 if (s < spp) {
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
                 } else { // pixel finished: mean, sqrt gamma, fp32 + unorm8 stores (src/render_megakernel.cpp:154-158)
                     live = false, pixel_finished = true;
                     const float n = (float)spp;
-                    const f3 c = mk3(__builtin_sqrtf(color.x / n), __builtin_sqrtf(color.y / n), __builtin_sqrtf(color.z / n));
+                    const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
                     const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
                     if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
                     if (out_u8)
@@ -433,8 +441,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         __builtin_amdgcn_s_setprio(1);
 #endif
     }
-    const unsigned long long total = wave_sum_u64(rays);
-    if (lane == 0 && total) atomicAdd(ray_counter, total);
+    if (lane == 0 && wave_rays) atomicAdd(ray_counter, wave_rays);
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
@@ -922,7 +929,8 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     bool live = false;
     RefillPolicy refill; // idle lanes that trigger a fetch of queue slots: set per wave from the pixels (or paths) it finishes
     RayState r{};
-    uint32_t id = 0, rng = 0, depth = 0, rays = 0;
+    uint32_t id = 0, rng = 0, depth = 0;
+    unsigned long long wave_rays = 0; // rays this wave traced beyond the queue entries' first (wave-uniform: a scalar pair)
     uint32_t samples_left = 0;  // samples of this lane's pixel still to render in this launch, the current one included
     bool first_counted = false; // the current path's first ray is a queue entry (counted by the host as the queue's length)
     // SHOOT, experiment (RT_WF_SHOOT_TAIL=1, bit 31 of chunk_slots): near the queue's end a wave claims a SHARE of what is left instead of a
@@ -1084,8 +1092,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         __builtin_amdgcn_s_setprio(0);
 #endif
         bool requeue = false, slot_finished = false, hand_on = false;
+        // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes): every other ray counts here
+        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth)));
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
-            if (!(first_counted && depth == first_depth)) rays++; // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes)
             f3 res;
             const bool done = shade_bounce(S, rng, r, T.best, res);
             depth++;
@@ -1188,8 +1197,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         __builtin_amdgcn_s_setprio(2);
 #endif
     }
-    const unsigned long long total = wave_sum_u64(rays);
-    if (lane == 0 && total) atomicAdd(extra_rays, total);
+    if (lane == 0 && wave_rays) atomicAdd(extra_rays, wave_rays);
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
         atomicAdd(stats_out + 2, (unsigned long long)ws.leaf_steps), atomicAdd(stats_out + 3, (unsigned long long)ws.leaf_lanes);
