@@ -87,9 +87,13 @@ RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), 
 
 // the part of one bounce after the closest-hit query: unpack halves -> shade_hit -> repack (the body of
 // render_pixel's loop, src/render_megakernel.cpp:34-55, and of shoot_rays, src/render_wavefront.cpp:245-291)
-RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result) {
-    f3 org = r.org;
-    f3 dir = ray_dir(r);
+// FROM_TRAV (the kernels whose lanes keep a ray across shading rounds): origin and direction are READ from the traversal state — T.o
+// and T.d are r.org and h2f(r.dir) exactly, trav_begin put them there — so that r.org / r.dir are written here and consumed by the
+// trav_begin (or the queue store) that follows, live only inside the round: six lane registers less through the traversal loop.
+template <bool FROM_TRAV = false>
+RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr) {
+    f3 org = FROM_TRAV ? T->o : r.org;
+    f3 dir = FROM_TRAV ? T->d : ray_dir(r);
     f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
     f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
     const bool done = shade_hit(S, rng, h, org, dir, att, rad, result);
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
 #endif
         if (live && T.cur == kTravDone) {
             f3 res;
-            const bool done = shade_bounce(S, rng, r, T.best, res);
+            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
             depth++;
             bool killed = false;
             if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
@@ -1096,7 +1100,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth)));
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
             f3 res;
-            const bool done = shade_bounce(S, rng, r, T.best, res);
+            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
             depth++;
             bool ends = done;
             if (done) {
