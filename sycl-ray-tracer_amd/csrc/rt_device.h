@@ -498,7 +498,38 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 #undef RT_CHILD
 #else
     u32x4 w0, w1, w2, chw;
-#if RT_NODE_OFFSETS // T.cur = byte offset of the node (rt_types.h)
+#ifndef RT_FETCH_ASM
+#define RT_FETCH_ASM 0
+#endif
+#if RT_NODE_OFFSETS && RT_FETCH_ASM
+    // The node fetch as ONE instruction block (experiment). Lanes at a node of the tree's top read the LDS copy, the others global memory,
+    // into the SAME sixteen registers: no lane is written twice, but the compiler sees two writes to one register and, in the C++ form
+    // below, puts an s_waitcnt vmcnt(0) for the global loads BEFORE the LDS reads — a whole L2 latency and then an LDS latency, one
+    // after the other, in every inner step. Here both are issued back to back and waited for together.
+    {
+        lmask sv;
+        const uint32_t la = (uint32_t)(size_t)top.w0 + ((uint32_t)T.cur >> 2); // planes back to back, kTopNodes * 16 bytes apart (RT_TRAVERSAL_LDS)
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "v_cmp_gt_i32_e32 vcc, %[topb], %[cur]\n\t"
+            "s_and_b64 exec, %[sv], vcc\n\t"
+            "ds_read_b128 %[w0], %[la]\n\t"
+            "ds_read_b128 %[w1], %[la] offset:%[o1]\n\t"
+            "ds_read_b128 %[w2], %[la] offset:%[o2]\n\t"
+            "ds_read_b128 %[w3], %[la] offset:%[o3]\n\t"
+            "s_andn2_b64 exec, %[sv], vcc\n\t"
+            "global_load_dwordx4 %[w0], %[cur], %[base]\n\t"
+            "global_load_dwordx4 %[w1], %[cur], %[base] offset:16\n\t"
+            "global_load_dwordx4 %[w2], %[cur], %[base] offset:32\n\t"
+            "global_load_dwordx4 %[w3], %[cur], %[base] offset:48\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)"
+            : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(chw), [sv] "=&s"(sv)
+            : [cur] "v"(T.cur), [la] "v"(la), [base] "s"(S.nodes), [topb] "s"(top.count * 64), [o1] "n"(kTopNodes * 16), [o2] "n"(2 * kTopNodes * 16),
+              [o3] "n"(3 * kTopNodes * 16)
+            : "vcc", "memory");
+    }
+#elif RT_NODE_OFFSETS // T.cur = byte offset of the node (rt_types.h)
     if (T.cur < top.count * 64) { // top of the tree: LDS, 16 bytes per node and plane
         const uint32_t o = (uint32_t)T.cur >> 2;
         w0 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w0 + o), w1 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w1 + o);

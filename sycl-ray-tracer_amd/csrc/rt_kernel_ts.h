@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(kTsBlock, RT_TS_OCC) k_megakernel_ts(SceneDev 
                                                                          uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                                          uint8_t* __restrict__ out_u8, unsigned long long* __restrict__ ray_counter,
                                                                          TsSlots sl, unsigned long long* __restrict__ stats_out) {
-    __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_w2[kTopNodes], top_ch[kTopNodes];
+    __shared__ u32x4 top_all[4 * kTopNodes]; // the four planes back to back (trav_inner's fetch addresses them from one base)
+    u32x4 *const top_w0 = top_all, *const top_w1 = top_all + kTopNodes, *const top_w2 = top_all + 2 * kTopNodes, *const top_ch = top_all + 3 * kTopNodes;
     __shared__ int32_t lds_stack[kLdsStack * kTsTLanes];
     __shared__ uint32_t ring_t[kTsRing], ring_s[kTsRing];
     __shared__ int32_t ctl[12]; // 0-2 T queue head / tail / avail, 3-5 S queue, 6 live slots, 7 waves still initialising, 8 error

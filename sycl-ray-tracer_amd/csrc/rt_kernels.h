@@ -71,7 +71,8 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK), 0u};
 #else
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
-    __shared__ u32x4 top_w0[kTopNodes], top_w1[kTopNodes], top_w2[kTopNodes], top_ch[kTopNodes];       \
+    __shared__ u32x4 top_all[4 * kTopNodes]; /* the four planes back to back: trav_inner's fetch addresses them from ONE base */ \
+    u32x4 *const top_w0 = top_all, *const top_w1 = top_all + kTopNodes, *const top_w2 = top_all + 2 * kTopNodes, *const top_ch = top_all + 3 * kTopNodes; \
     __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
     int32_t spill[kStackSize - kLdsStack];                                                             \
     const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
