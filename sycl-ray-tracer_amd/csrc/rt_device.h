@@ -764,7 +764,7 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         float4 a = tri_ld4(p4), b = tri_ld4(p4 + 16);
         float2 c = tri_ld2(p4 + 32);
         uint32_t k = 1;
-        for (; k < 4u; ++k) {
+        for (; k < (uint32_t)kMaxLeafTris; ++k) {
             if (__ballot(k <= rem) == 0ull) break;
             float4 na = a, nb = b;
             float2 nc = c;
@@ -1009,6 +1009,12 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const float4* sp = reinterpret_cast<const float4*>(S.shade + h.tri);
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
 #endif
+#ifndef RT_SHADE_EARLY_D
+#define RT_SHADE_EARLY_D 1 // experiment: the incoming direction normalised while the shading record is in flight
+#endif
+#if RT_SHADE_EARLY_D
+    const f3 d = normalize3(dir);
+#endif
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
@@ -1064,7 +1070,9 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
                      (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
     const f3 normal = normalize3(g);
+#if !RT_SHADE_EARLY_D
     const f3 d = normalize3(dir);
+#endif
     f3 sdir, satt;
 #if RT_EARLY_TEXEL
     if (scatter<true>(S, mat, rng, d, normal, tu, tv, sdir, satt, texel)) {

@@ -65,7 +65,9 @@ static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 #define RT_NODE_OFFSETS 1
 #endif
 #ifndef RT_MAX_LEAF_TRIS
-#define RT_MAX_LEAF_TRIS 4
+#define RT_MAX_LEAF_TRIS 2 // round 3: 4 -> 2, +1.1 % on the atrium (whose SAH tree had a few 3- and 4-triangle leaves: a whole-leaf step runs as many tests as the
+                           // wave's LARGEST leaf), -0.5 % on the voxel terrain (one block face = 2 triangles per leaf either way); 3: +-0. The whole-leaf loop is
+                           // bounded by this constant (rt_device.h, trav_leaf)
 #endif
 constexpr int kMaxLeafTris = RT_MAX_LEAF_TRIS; // 1..4 (the leaf code keeps count - 1 in two bits)
 constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64
