@@ -459,8 +459,10 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 #define RT_INTERLEAVE 0
 #endif
 #ifndef RT_SORT_CE
-#define RT_SORT_CE 4 // 5: full sorting network. 4 (default): nearest and farthest exact, the middle two in either order (-18 issue cycles per
-                     // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3: only the nearest exact (+-0)
+#define RT_SORT_CE 3 // 5: full sorting network. 4 (rounds 2-3): nearest and farthest exact, the middle two in either order (-18 issue cycles per
+                     // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3 (default since the end of round 3): only the
+                     // nearest exact, the other hits pushed in any order — +-0 when first measured, +0.6 / +1.3 % (atrium megakernel / wavefront) and
+                     // +2.3 % (voxel terrain) on the final kernels, where an instruction less weighs more than the order of the far children
 #endif
 RT_DEV TravSigns trav_signs(const Trav& T) { return TravSigns{lanes(T.ix < 0.0f), lanes(T.iy < 0.0f), lanes(T.iz < 0.0f)}; }
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg) {
