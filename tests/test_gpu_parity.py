@@ -463,6 +463,31 @@ def test_schedule_environment_shim_maps_onto_the_api(gpu_scenes, oracle, monkeyp
         r.close()
 
 
+@pytest.mark.parametrize("env", [{"RT_WF_SHOOT_TAIL": "0"}, {"RT_WF_SHOOT_TAIL": "0", "RT_WF_SHOOT_CHUNK": "32"}, {"RT_WF_SHOOT_STATIC_PCT": "0", "RT_WF_SHOOT_CHUNK": "16"},
+                                 {"RT_WF_SHOOT_STATIC_PCT": "100"}, {"RT_WF_SHOOT_STATIC_PCT": "40", "RT_WF_SHOOT_CHUNK": "1024"}, {}])
+def test_shoot_queue_claims_keep_the_frame(gpu_scenes, oracle, monkeypatch, env):
+    """SHOOT's input claims (rt_mi355x.hip: wf_shoot_tail): a static share of the queue in equal parts plus guided claims of what is left
+    (the default), fixed chunks (RT_WF_SHOOT_TAIL=0), the extremes of the static share and of the claim size — which ray a wave traces
+    never changes a pixel: frame, unorm8 image and ray count are the oracle's on a frame whose queues are longer than one claim per wave
+    and on one that fits a single wave's static part, on one stream lane and on three."""
+    for name, kw, (w, h), depth, spp in (("atrium", {"detail": 1}, (512, 288), 6, 2), ("cornell", {}, (40, 24), 8, 3)):
+        gs = gpu_scenes(name, **kw)
+        sd = gs.desc
+        cam = Camera.for_scene(sd, (w, h))
+        f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp, use_bvh=(name == "atrium"))
+        for lanes in (1, 3):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            r = WavefrontRenderer(gs, (w, h), depth, spp)
+            for k in env:
+                monkeypatch.delenv(k)
+            r.set_schedule(finish_depth=ALL_BOUNCES, fused_bounce=True, stream_lanes=lanes)
+            got = r.render_frame(cam)
+            assert got.kernels["wf_shoot"] == lanes * spp * depth and got.kernels["wf_finish"] == 0
+            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} SHOOT claims {env} on {lanes} lanes")
+            r.close()
+
+
 @pytest.mark.parametrize("finish_depth", [0, 1, 3, 7, 8, 99, ALL_BOUNCES])
 def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, finish_depth):
     """The wavefront renderer's schedule: the first rt_schedule.finish_depth bounces launch by launch (EXTEND + SHADE with global
