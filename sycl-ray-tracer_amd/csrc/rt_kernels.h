@@ -923,6 +923,14 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     uint32_t idle_polls = 0;                                                       // wave-uniform: consecutive iterations with nothing to trace
     const uint32_t total_entries = REQ ? n * (n_samples - 1u) : 0u;                // P
     const auto accum_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)accum, 0, (int)(n * 16u), 0x00020000); // REQ: 16-byte sc1 accesses
+    // One launch per frame: a lane renders all samples of its pixel and makes every camera ray but the first itself. Its pixel's x and
+    // global row were four integer divisions per SAMPLE (id % width, id / width, and the two of tile_global_row: ~100 instructions of a
+    // ~600-instruction shading round that nearly always holds a lane starting a sample); they are now taken once per PIXEL and kept,
+    // packed, in one LDS word per lane (images of up to 65,535 x 65,535; larger ones divide as before).
+    __shared__ uint32_t xg_lds[RT_MEGA_BLOCK];
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + threadIdx.x;
+    const bool xg_packed = camp->width < 65536 && camp->height < 65536;
     bool chunk_dq = false; // REQ: the wave's current chunk is a range of POSITIONS of the dynamic queue
     bool drained = false;  // REQ: the dynamic queue has no position left (wave-uniform)
     // REQ: this lane holds a position of the dynamic queue and polls it. A waiting lane has no pixel, so its position lives in `id` and
@@ -1049,6 +1057,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                                 rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
                                 depth = first_depth;
                                 samples_left = n_samples, first_counted = !holes;
+                                if (!REQ && n_samples > 1u && xg_packed) { // the pixel's coordinates for its later camera rays: two divisions ONCE per pixel
+                                    const uint32_t w = (uint32_t)camp->width;
+                                    *xg_p = (id % w) | ((uint32_t)tile_global_row(tile, (int)(id / w)) << 16);
+                                }
                                 trav_begin(T, r.org, ray_dir(r), stack);
                                 live = true;
                             }
@@ -1127,8 +1139,14 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             }
             if (!REQ && ends && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
                 const CameraDev cam = *camp;
-                const int x = (int)(id % (uint32_t)cam.width), ly = (int)(id / (uint32_t)cam.width);
-                r = camera_ray(cam, x, tile_global_row(tile, ly), rng);
+                int x, gy;
+                if (xg_packed) { // (x, global row) as the lane noted them when it took the pixel: no integer division per sample
+                    const uint32_t xg = *xg_p;
+                    x = (int)(xg & 0xFFFFu), gy = (int)(xg >> 16);
+                } else {
+                    x = (int)(id % (uint32_t)cam.width), gy = tile_global_row(tile, (int)(id / (uint32_t)cam.width));
+                }
+                r = camera_ray(cam, x, gy, rng);
                 depth = 0, first_counted = false;
                 ends = false;
             }
