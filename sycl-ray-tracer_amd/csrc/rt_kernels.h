@@ -197,6 +197,9 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
 #ifndef RT_MEGA_MISS_ROUND
 #define RT_MEGA_MISS_ROUND 0 // lanes waiting with a MISS that trigger a round of their own (experiment, measured: DESIGN.md §6); 0 = off
 #endif
+#ifndef RT_MEGA_LINGER
+#define RT_MEGA_LINGER 0 // experiment: traversal iterations a wave may add after the shading threshold is reached while a lane is on its last stack entry
+#endif
 #ifndef RT_MEGA_PRIO
 #define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
                        // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
@@ -346,9 +349,21 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         bool miss_round = false; // RT_MEGA_MISS_ROUND: this round only ends the paths that missed
         (void)miss_round;
         const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
+        uint32_t lingered = 0; // RT_MEGA_LINGER
+        (void)lingered;
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) break;
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) {
+#if RT_MEGA_LINGER
+                // the threshold is reached, but a lane on its LAST stack entry is about to finish: a round that starts now makes it wait for
+                // the whole next cycle; a few more steps take it along (at most RT_MEGA_LINGER more iterations, never beyond 90 % waiting)
+                const bool soon = live && !waiting && T.sp == stack.base;
+                if (lingered >= RT_MEGA_LINGER || __ballot(soon) == 0ull || (uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * 90u) break;
+                ++lingered;
+#else
+                break;
+#endif
+            }
 #if RT_MEGA_MISS_ROUND
             if ((uint32_t)__popcll(__ballot(waiting && T.best.tri == kNoTri)) >= RT_MEGA_MISS_ROUND) {
                 miss_round = true;
