@@ -209,7 +209,9 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
  *                       value >= max_depth) = the reference's per-bounce schedule.
  *   samples_per_launch  samples of a pixel one k_wf_finish launch renders. 0 = all of them: ONE launch per frame (default).
  *   stream_lanes        interleaved sub-tiles rendered on HIP streams of their own. 0 = automatic (1 for the one-launch
- *                       schedule, 3 for fused_bounce, 2 otherwise).
+ *                       schedule, 3 for a launch or launch pair per bounce all the way down, 2 otherwise). HIP serves streams from
+ *                       GPU_MAX_HW_QUEUES hardware queues (default 4): the library sets that variable to 8 when it is loaded unless
+ *                       it is set already; a host that initialises HIP before loading the library should set it itself.
  *   requeue             with samples_per_launch > 1: 1 = a pixel between two samples goes through a device-wide dynamic queue
  *                       (breadth first), 0 = it stays in its lane (depth first), -1 = automatic.
  *   reorder, matsort    SURVEY 8(f) row f-3, per-bounce schedule only: k_wf_shade bins a block's survivors by direction octant

@@ -305,10 +305,17 @@ bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch ==
 // (the split EXTEND + SHADE pipeline of every bounce on 1 / 2 / 3 lanes: 4166 / 4979 / 5213 Mrays/s on the atrium at 1080p, 64 spp when the host
 // thread does nothing else — but three lanes are 4,038 launches per frame, and in a process that also runs torch (bench.py) the host enqueues
 // them slower than the device consumes them: 333 instead of 208 ms. Two lanes, 2,692 launches, stay ahead of the device: the default.)
-// (stream lanes by default: 1 for the one-launch schedule, 3 for one fused kernel per bounce — 2,118 launches per 64-spp frame, each lane's
-//  launches asking for 2 of the 6 wave slots per SIMD; 4 lanes leave each launch one wave per SIMD and halve the rate — 2 otherwise)
+// (stream lanes by default: 1 for the one-launch schedule, 3 for a launch (pair) per bounce all the way — 2,118 / 4,038 launches per 64-spp frame;
+//  SHOOT's launches ask for 2 of the 6 wave slots per SIMD each, 4 lanes leave them one and lose a fifth — 2 otherwise.)
+// HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues, 4 by default: with the frame's stream, three lane streams and one stream of
+// the host framework (torch, in bench.py) two lanes shared a queue and ran one after the other — the split pipeline on three lanes took 314 ms
+// per frame inside bench.py against 190 ms from a bare process, and SHOOT on four lanes halved its rate everywhere. The library therefore asks
+// for 8 queues when it is loaded (unless the variable is set): effective if that happens before the process's first HIP call.
+__attribute__((constructor)) void rt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 uint32_t wf_stream_lanes(const rt_renderer* r) {
-    return r->sched.stream_lanes ? std::min(r->sched.stream_lanes, 8u) : (wf_one_launch(r) ? 1u : r->sched.fused_bounce ? 3u : 2u);
+    if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u);
+    if (wf_one_launch(r)) return 1u;
+    return r->sched.fused_bounce || r->sched.finish_depth >= r->max_depth ? 3u : 2u;
 }
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile

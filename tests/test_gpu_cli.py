@@ -101,11 +101,11 @@ def test_cli_tiles_a_frame_over_several_devices_in_one_process(rtlib, oracle, tm
     assert p.returncode == 1 and "does not exist" in p.stdout
 
 
-@pytest.mark.parametrize("schedule,expect", [("per-bounce", "extend 30, shade 30, shoot 0, finish 0"), ("per-bounce-fused", "extend 0, shade 0, shoot 45, finish 0"),
+@pytest.mark.parametrize("schedule,expect", [("per-bounce", "extend 45, shade 45, shoot 0, finish 0"), ("per-bounce-fused", "extend 0, shade 0, shoot 45, finish 0"),
                                              ("per-sample", "extend 0, shade 0, shoot 0, finish 6")])
 def test_cli_schedule_flag_selects_and_reports_the_schedule(rtlib, oracle, tmp_path, schedule, expect):
     """--schedule: the wavefront renderer's other schedules through the CLI (rt_renderer_set_schedule in the C++ adapter); the line it
-    prints comes from rt_stats (what ran: 3 samples x 5 bounces on 2 stream lanes, 3 for the fused kernel), and PNG and ray count stay the oracle's."""
+    prints comes from rt_stats (what ran: 3 samples x 5 bounces on 3 stream lanes; a launch per sample: 2 lanes), and PNG and ray count stay the oracle's."""
     from PIL import Image
     w, h, depth, spp = 96, 64, 5, 3
     glb = REPO / "assets" / "cube.glb"

@@ -414,8 +414,9 @@ def test_wavefront_schedule_knobs_keep_the_frame(gpu_scenes, oracle, sched):
         back = r.get_schedule()
         assert all(getattr(back, k) == int(v) for k, v in sched.items())
         got = r.render_frame(cam)
-        # automatic: 1 for the one-launch schedule, 3 for one fused kernel per bounce, else 2
-        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0 else 3 if sched.get("fused_bounce") else 2)
+        # automatic: 1 for the one-launch schedule, 3 for a launch (pair) per bounce all the way down or one fused kernel per bounce, else 2
+        lanes = sched.get("stream_lanes", 0) or (1 if sched.get("samples_per_launch", 0) == 0 and sched.get("finish_depth", 0) == 0
+                                                else 3 if sched.get("fused_bounce") or sched.get("finish_depth", 0) >= depth else 2)
         assert got.stream_lanes == lanes and got.finish_depth == min(sched.get("finish_depth", 0), depth)
         assert got.kernels["wf_init"] == got.kernels["wf_resolve"] == lanes
         fused = bool(sched.get("fused_bounce"))  # one SHOOT launch per bounce instead of the EXTEND + SHADE pair
@@ -444,7 +445,7 @@ def test_schedule_environment_shim_maps_onto_the_api(gpu_scenes, oracle, monkeyp
     w, h, depth, spp = 96, 64, 6, 4
     cam = Camera.for_scene(sd, (w, h))
     f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp)
-    cases = [({"RT_WF_FINISH_DEPTH": "99", "RT_WF_REORDER": "1"}, dict(finish_depth=99, reorder=1), ("wf_shade_reorder", 2 * spp * depth)),
+    cases = [({"RT_WF_FINISH_DEPTH": "99", "RT_WF_REORDER": "1"}, dict(finish_depth=99, reorder=1), ("wf_shade_reorder", 3 * spp * depth)),
              ({"RT_WF_STREAMS": "3"}, dict(stream_lanes=3, samples_per_launch=1), ("wf_finish", 3 * spp)),
              ({"RT_WF_REQUEUE": "0"}, dict(requeue=0, samples_per_launch=1), ("wf_finish", 2 * spp)),
              ({"RT_WF_SAMPLES_PER_LAUNCH": "2"}, dict(samples_per_launch=2), ("wf_finish_requeue", 2 * 2)),
@@ -504,7 +505,7 @@ def test_wavefront_finish_depth_keeps_the_frame(gpu_scenes, oracle, finish_depth
         r.set_schedule(finish_depth=finish_depth)
         got = r.render_frame(cam)
         d0 = min(finish_depth, depth)
-        lanes = 1 if finish_depth == 0 else 2
+        lanes = 1 if finish_depth == 0 else 3 if finish_depth >= depth else 2
         assert got.finish_depth == d0 and got.stream_lanes == lanes
         assert got.kernels["wf_extend"] == got.kernels["wf_shade"] == lanes * spp * d0
         assert got.kernels["wf_finish"] == (0 if d0 == depth else lanes * (spp if d0 else 1))
