@@ -41,25 +41,16 @@ RT_DEV f3 cross3(f3 a, f3 b) {
 // rt_probe_rounding runs the check on the functions below, in the GPU test suite: tests/test_gpu_parity.py). Outside those ranges
 // (zero, denormals, huge, inf, NaN, negative radicands) a wave-uniform branch takes the compiler's IEEE sequence, so the functions
 // equal the IEEE expressions everywhere; inside, a normalisation costs 14 instructions instead of 28 + 11.
-#ifndef RT_FAST_RN
-#define RT_FAST_RN 1
-#endif
-#ifndef RT_FAST_RN_TRI
-#define RT_FAST_RN_TRI RT_FAST_RN // ... in the triangle test's 1 / det too
-#endif
 RT_DEV float rcp_rn(float x) { // == 1.0f / x
-#if RT_FAST_RN
     const uint32_t t = __float_as_uint(x) + __float_as_uint(x); // the sign shifted out
     const bool ok = t - 0x01000000u < 0xFC000000u;              // biased exponent 1 .. 252
     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
         const float y = __builtin_amdgcn_rcpf(x);
         return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
     }
-#endif
     return 1.0f / x;
 }
 RT_DEV float inv_sqrt2(float x) { // == 1.0f / sqrtf(x): two roundings, as glm::normalize / sycl::normalize
-#if RT_FAST_RN
     const bool ok = __float_as_uint(x) - 0x0C800000u < 0x73000000u; // positive, biased exponent 25 .. 254
     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
         const float r = __builtin_amdgcn_rsqf(x);
@@ -70,7 +61,6 @@ RT_DEV float inv_sqrt2(float x) { // == 1.0f / sqrtf(x): two roundings, as glm::
         const float y = __builtin_amdgcn_rcpf(s);
         return __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
     }
-#endif
     return 1.0f / __builtin_sqrtf(x);
 }
 // glm::normalize / sycl::normalize: v * (1 / sqrt(dot(v,v)))
@@ -160,24 +150,7 @@ struct Hit {
 // Moller-Trumbore on the precomputed (v0, e1, e2); barycentrics in Embree's convention
 // P = (1-u-v) v0 + u v1 + v v2. Edge tests on the sign-corrected numerators; one division per
 // accepted candidate. Minimum t wins, equal t -> lowest global index (order independent).
-// RT_SHADE_PREFETCH=1 (round 3, an experiment, measured and OFF): the renderers' traversal touches the shading record of every NEW
-// closest hit the moment the triangle test accepts it — one dword of the 64-byte record, loaded into a per-wave LDS sink that nobody
-// reads (global_load_lds: no VGPR is written, so nothing can be clobbered when the data arrives) — so that the line is on its way into
-// the L2 while the ray works through the rest of its stack and then waits for its wave's shading round. The idea came from measuring
-// how much the round's fetch latency weighs: the same fetches with the non-temporal hint (RT_SHADE_NT) cost 25 % of the frame. The
-// prefetch costs 6.4 % instead of gaining (143.7 -> 153.4 ms, bit-exact): vector memory loads return IN ORDER, so the next inner
-// step's s_waitcnt for its node fetch also waits for the prefetch issued before it — a miss into the Infinity Cache that the traversal
-// never had on its critical path before. gfx950 has no fire-and-forget vector prefetch (scalar loads need uniform addresses).
-#ifndef RT_SHADE_PREFETCH
-#define RT_SHADE_PREFETCH 0
-#endif
-RT_DEV void shade_prefetch(const void* shade_base, uint32_t tri, uint32_t lds_sink) {
-    typedef __attribute__((address_space(1))) const void gvoid;
-    typedef __attribute__((address_space(3))) void lvoid;
-    __builtin_amdgcn_global_load_lds((gvoid*)(reinterpret_cast<const char*>(shade_base) + (uint32_t)(tri << 6)), (lvoid*)(size_t)lds_sink, 4, 0, 0);
-}
-template <bool PF = false>
-RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best, const void* shade_base = nullptr, uint32_t lds_sink = 0) { // the record's 10 live dwords
+RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best) { // the record's 10 live dwords
     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     const uint32_t gidx = __float_as_uint(c.y);
     const f3 p = cross3(d, e2);
@@ -189,11 +162,7 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best, c
     const float un0 = dot3(tv, p), vn0 = dot3(d, q);
     const float un = un0 * sgn, vn = vn0 * sgn;
     if (!(un >= 0.0f && vn >= 0.0f && un + vn <= __builtin_fabsf(det))) return;
-#if RT_FAST_RN_TRI
     const float inv = rcp_rn(det);
-#else
-    const float inv = 1.0f / det;
-#endif
     const float t = dot3(e2, q) * inv;
     if (!(t > kTNear)) return;
     if (t < best.t || (t == best.t && gidx < best.tri)) {
@@ -201,7 +170,6 @@ RT_DEV void tri_test_regs(float4 a, float4 b, float2 c, f3 o, f3 d, Hit& best, c
         best.u = un0 * inv;
         best.v = vn0 * inv;
         best.tri = gidx;
-        if (PF && RT_SHADE_PREFETCH) shade_prefetch(shade_base, gidx, lds_sink);
     }
 }
 // the packed 40-byte device records are only 8-byte aligned: the loads say so (still one dwordx4 each: gfx950 needs dword alignment only)
@@ -231,37 +199,13 @@ RT_DEV void tri_test(const uint8_t* __restrict__ tr, f3 o, f3 d, Hit& best) {
 // one loop) was 27 %. The box test is a padded-box cull: it uses fma and an approximate reciprocal on
 // purpose (never visible in results).
 constexpr int32_t kTravDone = (int32_t)0x80000000;
-// RT_POSTPONE=1 (experiment): a lane that reaches a leaf while its wave keeps taking inner steps does not wait for the leaf vote:
-// it sets the leaf aside (one per lane), pops its stack and goes on with inner nodes; the leaf is tested at the wave's next leaf
-// step. The closest hit does not depend on the order of the tests (ties go to the lower triangle index), so results are unchanged;
-// what it costs is culling (nodes visited with a stale best.t) and a few instructions per step.
-#ifndef RT_POSTPONE
-#define RT_POSTPONE 0
-#endif
-#ifndef RT_PP_VOTE
-#define RT_PP_VOTE 0
-#endif
-#ifndef RT_STATS_STALE
-#define RT_STATS_STALE 0
-#endif
-
 struct Trav {
     f3 o, d;              // ray (d unnormalised, as stored)
     float ix, iy, iz;     // 1/d (|d| clamped away from 0)
     float ox, oy, oz;     // -o/d
     Hit best;
     int32_t cur;
-#if RT_WIDE_NODES
-    uint32_t nx, ny, nz; // byte offsets of the ray's NEAR plane words inside a WideNode (x: 0 / 16, y: 32 / 48, z: 64 / 80); far = near ^ 16
-#endif
     uint32_t sp; // LDS byte address of the lane's next free stack entry (TravStack::base = empty); beyond the LDS part it keeps counting
-#if RT_STATS_STALE
-    float cur_t = 0.0f; // entry distance of `cur` as computed when it was pushed / descended into
-#endif
-#if RT_POSTPONE
-    int32_t pend = kTravDone; // a postponed leaf (same code as `cur`) or kTravDone: none. Invariant: cur == kTravDone => pend == kTravDone
-                              // (a pop from an empty stack hands the postponed leaf back to `cur`)
-#endif
 };
 
 struct TravStack;
@@ -279,17 +223,8 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
     const float dz = __builtin_fabsf(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z;
     T.ix = __builtin_amdgcn_rcpf(dx), T.iy = __builtin_amdgcn_rcpf(dy), T.iz = __builtin_amdgcn_rcpf(dz);
     T.ox = -o.x * T.ix, T.oy = -o.y * T.iy, T.oz = -o.z * T.iz;
-#if RT_WIDE_NODES
-    T.nx = T.ix < 0.0f ? 16u : 0u, T.ny = T.iy < 0.0f ? 48u : 32u, T.nz = T.iz < 0.0f ? 80u : 64u;
-#endif
     T.cur = 0; // root
-#if RT_STATS_STALE
-    T.cur_t = 0.0f;
-#endif
     T.sp = stack_base(st); // empty stack
-#if RT_POSTPONE
-    T.pend = kTravDone;
-#endif
 }
 
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (entry-major, lane-minor:
@@ -299,19 +234,12 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
 // v_sub_u32 + ds_read, with no index -> address arithmetic (v_lshl_or_b32 is a 4-cycle instruction) and no per-push depth test:
 // a step asks ONCE, wave-uniformly, whether every lane's next three pushes and its pop stay inside the LDS part (they nearly
 // always do) and only otherwise takes the general routines, which turn the address back into an entry index.
-#ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12
-#endif
-constexpr int kLdsStack = RT_LDS_STACK;
+constexpr int kLdsStack = 12;
 typedef __attribute__((address_space(3))) int32_t lds_i32; // forces ds_read/ds_write (never flat_*)
 struct TravStack {
     uint32_t base;  // LDS byte address of this lane's entry 0
     int32_t* spill; // kStackSize - kLdsStack entries of scratch
     uint32_t pitch; // bytes from one entry of a lane to its next: 4 * threads per block (a power of two)
-    uint32_t pf_sink; // wave-uniform LDS byte address of this wave's 256-byte prefetch sink (shade_prefetch)
-#if RT_STATS_STALE
-    float* dstk = nullptr; // kStackSize entry distances (scratch)
-#endif
 };
 RT_DEV uint32_t stack_base(const TravStack& st) { return st.base; }
 RT_DEV lds_i32* lds_at(uint32_t addr) { return (lds_i32*)(size_t)addr; }
@@ -340,46 +268,19 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
         T.sp -= st.pitch;
         const uint32_t e = (T.sp - st.base) / st.pitch;
         T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
-#if RT_STATS_STALE
-        T.cur_t = st.dstk[e];
-#endif
     } else {
         T.cur = kTravDone;
     }
 }
-#if RT_STATS_STALE
-RT_DEV void stk_push_t(const TravStack& st, Trav& T, int32_t v, float t) {
-    st.dstk[(T.sp - st.base) / st.pitch] = t;
-    stk_push(st, T, v);
-}
-#endif
 
 // The first kTopNodes nodes of the breadth-first node array (the top ~5 levels of the BVH4) are staged in
 // LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes of 16 bytes per node (the node's
 // four 16-byte words), so that the 16-byte reads of different nodes spread over the banks. Measured on the atrium: 9.5 of the 17.9 inner-node
 // visits of an average ray fall into these nodes; taking them out of the vector L1 path (the first
 // versions were bound by L1 tag throughput: ~1 lane-load per cycle and CU) is worth more than any ALU saving.
-#ifndef RT_TOP_NODES
-#if RT_WIDE_NODES
-#define RT_TOP_NODES 170 // 128-byte nodes: the same 21.8 KB of LDS
-#else
-#define RT_TOP_NODES 341
-#endif
-#endif
-constexpr int kTopNodes = RT_TOP_NODES;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-#if RT_WIDE_NODES
-struct TopTree {
-    uint32_t base; // LDS byte address of node 0's record (128 bytes per node, as in memory)
-    int32_t bytes; // nodes staged x 128 (0 = none): a node reference (byte offset) below this is read from LDS
-};
-RT_DEV void top_tree_fill(const SceneDev& S, u32x4* rec, int32_t count) {
-    const u32x4* np = reinterpret_cast<const u32x4*>(S.wnodes);
-    for (int32_t i = (int32_t)threadIdx.x; i < count * 8; i += (int32_t)blockDim.x) rec[i] = np[i];
-}
-#else
 struct TopTree {
     lds_u32x4* w0; // origin.xyz, scale.x
     lds_u32x4* w1; // qlo_x, qhi_x, qlo_y, qhi_y
@@ -397,7 +298,6 @@ RT_DEV void top_tree_fill(const SceneDev& S, u32x4* w0, u32x4* w1, u32x4* w2, u3
         ch[i] = np[3];
     }
 }
-#endif
 
 // ---- instruction selection helpers (profiles/r02_valu_calibration.json) ------------------------------------------------
 // The traversal kernels are bound by VALU issue cycles, and on gfx950 a select is cheap or dear by its ENCODING: v_cndmask_b32_e64
@@ -438,100 +338,11 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 //   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
 // The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
 // min/max pairing is needed.
-// VALU budget of one step (cycles per wave, from the calibrated costs: fma/mul 2, everything else 4): 3 mul + 3 fma 12, sign selects
-// 3 cmp + 6 sel 36, per child 6 cvt + 6 fma + max/max3 + min/min3 + cmp + sel 60 (x4 = 240), sort RT_SORT_CE x (cmp + 4 sel) 20 each,
-// pushes / pop ~60: ~420 with the 5-comparator network, ~380 with the 3-comparator one.
-// Two experiments kept behind flags, both bit-exact, both OFF (megakernel, atrium 1080p 16 spp, two runs each, default 7040 / 7039 Mrays/s):
-//   RT_SIGN_XOR=1    near / far plane words picked with v_ashrrev + xor / and instead of v_cmp + v_cndmask: 7047 / 7071 (noise)
-//   RT_LEAF_UNROLL=1 whole-leaf step unrolled over two register sets (no record copies, -100 static issue cycles): 6975 / 6944 (-1.2 %)
-#ifndef RT_STATS_LEAFWAIT
-#define RT_STATS_LEAFWAIT 0
-#endif
-// RT_STATS_STALE=1 (diagnostic variant, RT_KERNEL_STATS runs): every stack entry carries its entry distance in scratch; the "top nodes" counter counts
-// the inner-step lanes whose node lies beyond best.t by now (a stale pop), "live lanes/step" the same for leaf steps
-#ifndef RT_SIGN_XOR
-#define RT_SIGN_XOR 0
-#endif
-#ifndef RT_LEAF_UNROLL
-#define RT_LEAF_UNROLL 0
-#endif
-#ifndef RT_INTERLEAVE
-#define RT_INTERLEAVE 0
-#endif
-#ifndef RT_SORT_CE
-#define RT_SORT_CE 3 // 5: full sorting network. 4 (rounds 2-3): nearest and farthest exact, the middle two in either order (-18 issue cycles per
-                     // step, no measurable change in node visits: +0.3 % megakernel, +1.5 % wavefront). 3 (default since the end of round 3): only the
-                     // nearest exact, the other hits pushed in any order — +-0 when first measured, +0.6 / +1.3 % (atrium megakernel / wavefront) and
-                     // +2.3 % (voxel terrain) on the final kernels, where an instruction less weighs more than the order of the far children
-#endif
 RT_DEV TravSigns trav_signs(const Trav& T) { return TravSigns{lanes(T.ix < 0.0f), lanes(T.iy < 0.0f), lanes(T.iz < 0.0f)}; }
 RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg) {
     const float inf = __builtin_huge_valf();
     float k0, k1, k2, k3;
-#if RT_WIDE_NODES
-    // fp32 planes, near / far words picked by address: no conversions, no selects; t = plane * inv - o * inv in one fma per plane
-    u32x4 pnx, pfx, pny, pfy, pnz, pfz, chw;
-    if (T.cur < top.bytes) { // top of the tree: LDS
-        const uint32_t a = top.base + (uint32_t)T.cur;
-        pnx = *(lds_u32x4*)(size_t)(a + T.nx), pfx = *(lds_u32x4*)(size_t)(a + (T.nx ^ 16u));
-        pny = *(lds_u32x4*)(size_t)(a + T.ny), pfy = *(lds_u32x4*)(size_t)(a + (T.ny ^ 16u));
-        pnz = *(lds_u32x4*)(size_t)(a + T.nz), pfz = *(lds_u32x4*)(size_t)(a + (T.nz ^ 16u));
-        chw = *(lds_u32x4*)(size_t)(a + 96u);
-    } else {
-        const char* np = reinterpret_cast<const char*>(S.wnodes) + (uint32_t)T.cur;
-        pnx = *reinterpret_cast<const u32x4*>(np + T.nx), pfx = *reinterpret_cast<const u32x4*>(np + (T.nx ^ 16u));
-        pny = *reinterpret_cast<const u32x4*>(np + T.ny), pfy = *reinterpret_cast<const u32x4*>(np + (T.ny ^ 16u));
-        pnz = *reinterpret_cast<const u32x4*>(np + T.nz), pfz = *reinterpret_cast<const u32x4*>(np + (T.nz ^ 16u));
-        chw = *reinterpret_cast<const u32x4*>(np + 96);
-    }
-    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
-#define RT_CHILD(K, C)                                                                                                                     \
-    {                                                                                                                                     \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(__uint_as_float(pnx.C), T.ix, T.ox), __builtin_fmaf(__uint_as_float(pny.C), T.iy, T.oy)), \
-                                         __builtin_fmaxf(__builtin_fmaf(__uint_as_float(pnz.C), T.iz, T.oz), 0.0f));                      \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(__uint_as_float(pfx.C), T.ix, T.ox), __builtin_fmaf(__uint_as_float(pfy.C), T.iy, T.oy)), \
-                                         __builtin_fminf(__builtin_fmaf(__uint_as_float(pfz.C), T.iz, T.oz), T.best.t));                  \
-        K = sel(lanes(tn <= tf), inf, tn);                                                                                                \
-    }
-    RT_CHILD(k0, x)
-    RT_CHILD(k1, y)
-    RT_CHILD(k2, z)
-    RT_CHILD(k3, w)
-#undef RT_CHILD
-#else
     u32x4 w0, w1, w2, chw;
-#ifndef RT_FETCH_ASM
-#define RT_FETCH_ASM 0
-#endif
-#if RT_NODE_OFFSETS && RT_FETCH_ASM
-    // The node fetch as ONE instruction block (experiment). Lanes at a node of the tree's top read the LDS copy, the others global memory,
-    // into the SAME sixteen registers: no lane is written twice, but the compiler sees two writes to one register and, in the C++ form
-    // below, puts an s_waitcnt vmcnt(0) for the global loads BEFORE the LDS reads — a whole L2 latency and then an LDS latency, one
-    // after the other, in every inner step. Here both are issued back to back and waited for together.
-    {
-        lmask sv;
-        const uint32_t la = (uint32_t)(size_t)top.w0 + ((uint32_t)T.cur >> 2); // planes back to back, kTopNodes * 16 bytes apart (RT_TRAVERSAL_LDS)
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "v_cmp_gt_i32_e32 vcc, %[topb], %[cur]\n\t"
-            "s_and_b64 exec, %[sv], vcc\n\t"
-            "ds_read_b128 %[w0], %[la]\n\t"
-            "ds_read_b128 %[w1], %[la] offset:%[o1]\n\t"
-            "ds_read_b128 %[w2], %[la] offset:%[o2]\n\t"
-            "ds_read_b128 %[w3], %[la] offset:%[o3]\n\t"
-            "s_andn2_b64 exec, %[sv], vcc\n\t"
-            "global_load_dwordx4 %[w0], %[cur], %[base]\n\t"
-            "global_load_dwordx4 %[w1], %[cur], %[base] offset:16\n\t"
-            "global_load_dwordx4 %[w2], %[cur], %[base] offset:32\n\t"
-            "global_load_dwordx4 %[w3], %[cur], %[base] offset:48\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_waitcnt vmcnt(0) lgkmcnt(0)"
-            : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(chw), [sv] "=&s"(sv)
-            : [cur] "v"(T.cur), [la] "v"(la), [base] "s"(S.nodes), [topb] "s"(top.count * 64), [o1] "n"(kTopNodes * 16), [o2] "n"(2 * kTopNodes * 16),
-              [o3] "n"(3 * kTopNodes * 16)
-            : "vcc", "memory");
-    }
-#elif RT_NODE_OFFSETS // T.cur = byte offset of the node (rt_types.h)
     if (T.cur < top.count * 64) { // top of the tree: LDS, 16 bytes per node and plane
         const uint32_t o = (uint32_t)T.cur >> 2;
         w0 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w0 + o), w1 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w1 + o);
@@ -540,41 +351,16 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         const u32x4* np = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)T.cur);
         w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
     }
-#else
-    if (T.cur < top.count) { // top of the tree: LDS
-        w0 = top.w0[T.cur], w1 = top.w1[T.cur], w2 = top.w2[T.cur], chw = top.ch[T.cur];
-    } else {
-        const u32x4* np = reinterpret_cast<const u32x4*>(S.nodes + T.cur);
-        w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
-    }
-#endif
-#if RT_ORDERED // the grid steps' sign bits hold the node's ordering axis (rt_types.h): |step|, a free source modifier
-    const float ax = __builtin_fabsf(__uint_as_float(w0.w)) * T.ix;
-    const float ay = __builtin_fabsf(__uint_as_float(w2.z)) * T.iy;
-    const float az = __builtin_fabsf(__uint_as_float(w2.w)) * T.iz;
-#else
     const float ax = __uint_as_float(w0.w) * T.ix;
     const float ay = __uint_as_float(w2.z) * T.iy;
     const float az = __uint_as_float(w2.w) * T.iz;
-#endif
     const float bx = __builtin_fmaf(__uint_as_float(w0.x), T.ix, T.ox);
     const float by = __builtin_fmaf(__uint_as_float(w0.y), T.iy, T.oy);
     const float bz = __builtin_fmaf(__uint_as_float(w0.z), T.iz, T.oz);
-#if RT_SIGN_XOR
-    // near / far plane words by the direction sign without compares or selects: m = all ones where the component is negative
-    // (v_ashrrev_i32, 2 cycles), d = (lo ^ hi) & m, near = lo ^ d, far = hi ^ d — ten 2-cycle instructions per axis pair instead of
-    // one v_cmp + two v_cndmask (12 cycles)
-    const uint32_t mx = (uint32_t)(__float_as_int(T.ix) >> 31), my = (uint32_t)(__float_as_int(T.iy) >> 31), mz = (uint32_t)(__float_as_int(T.iz) >> 31);
-    const uint32_t dx = (w1.x ^ w1.y) & mx, dy = (w1.z ^ w1.w) & my, dz = (w2.x ^ w2.y) & mz;
-    const uint32_t qnx = w1.x ^ dx, qfx = w1.y ^ dx;
-    const uint32_t qny = w1.z ^ dy, qfy = w1.w ^ dy;
-    const uint32_t qnz = w2.x ^ dz, qfz = w2.y ^ dz;
-#else
     const lmask nx = sg.nx, ny = sg.ny, nz = sg.nz;
     const uint32_t qnx = sel(nx, w1.x, w1.y), qfx = sel(nx, w1.y, w1.x);
     const uint32_t qny = sel(ny, w1.z, w1.w), qfy = sel(ny, w1.w, w1.z);
     const uint32_t qnz = sel(nz, w2.x, w2.y), qfz = sel(nz, w2.y, w2.x);
-#endif
     // An absent child needs no test of its own: its box is stored inverted (qlo = 255, qhi = 0), which
     // makes entry > exit on every axis for either direction sign. (Pairing children into v_pk_fma_f32 costs
     // 4 cycles per pair, the same as two v_fma_f32.)
@@ -584,21 +370,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     // for any child, absent or not — so the child words are not tested here (an explicit kChildEmpty test per slot was measured at
     // 12 issue cycles of ~500 per step).
     int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
-#if RT_INTERLEAVE // experiment: every conversion directly followed by its fma (pinned with scheduling fences)
-#define RT_FENCE __builtin_amdgcn_sched_barrier(0);
-#define RT_CHILD(K, CVT)                                                                                  \
-    {                                                                                                    \
-        const float t0 = __builtin_fmaf(CVT(qnx), ax, bx); RT_FENCE                                       \
-        const float t1 = __builtin_fmaf(CVT(qny), ay, by); RT_FENCE                                       \
-        const float t2 = __builtin_fmaf(CVT(qnz), az, bz); RT_FENCE                                       \
-        const float t3 = __builtin_fmaf(CVT(qfx), ax, bx); RT_FENCE                                       \
-        const float t4 = __builtin_fmaf(CVT(qfy), ay, by); RT_FENCE                                       \
-        const float t5 = __builtin_fmaf(CVT(qfz), az, bz); RT_FENCE                                       \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, 0.0f));            \
-        const float tf = __builtin_fminf(__builtin_fminf(t3, t4), __builtin_fminf(t5, T.best.t));        \
-        K = sel(lanes(tn <= tf), inf, tn);                                                               \
-    }
-#else
 #define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
@@ -607,66 +378,11 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
                                          __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
         K = sel(lanes(tn <= tf), inf, tn);                                                               \
     }
-#endif
-#if RT_ORDERED
-#undef RT_CHILD
-#define RT_CHILD(H, CVT)                                                                                  \
-    {                                                                                                    \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
-                                         __builtin_fmaxf(__builtin_fmaf(CVT(qnz), az, bz), 0.0f));       \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(CVT(qfx), ax, bx), __builtin_fmaf(CVT(qfy), ay, by)), \
-                                         __builtin_fminf(__builtin_fmaf(CVT(qfz), az, bz), T.best.t));   \
-        H = lanes(tn <= tf);                                                                             \
-    }
-    // Children in stored order are front to back for a ray that travels up the node's ordering axis, back to front for one that
-    // travels down it. All the bookkeeping is lane MASKS in scalar registers (s_and / s_or / s_andn2: no vector instruction): which
-    // slot is the first hit in the lane's order (f0..f3), which of the others are pushed, far to near (pA, pB, pC). Vector work:
-    // three selects for the child to descend into, three for the pushed words, one compare for the order.
-    lmask h0, h1, h2, h3;
-    RT_CHILD(h0, ub0)
-    RT_CHILD(h1, ub1)
-    RT_CHILD(h2, ub2)
-    RT_CHILD(h3, ub3)
-#undef RT_CHILD
-    (void)k0, (void)k1, (void)k2, (void)k3, (void)inf;
-    {
-        const uint32_t rvb = (w0.w & __float_as_uint(T.ix)) | (w2.z & __float_as_uint(T.iy)) | (w2.w & __float_as_uint(T.iz));
-        const lmask R = lanes((int32_t)rvb < 0), F = ~R;
-        const lmask any = (h0 | h1) | (h2 | h3);
-        const lmask f0 = h0 & (F | ~(h1 | h2 | h3));
-        const lmask f1 = h1 & ((F & ~h0) | (R & ~(h2 | h3)));
-        const lmask f2 = h2 & ((F & ~(h0 | h1)) | (R & ~h3));
-        const lmask f3 = h3 & (R | ~(h0 | h1 | h2));
-        int32_t nxt = sel(f1, c0, c1);
-        nxt = sel(f2, nxt, c2);
-        nxt = sel(f3, nxt, c3);
-        const int32_t vA = sel(R, c3, c0), vB = sel(R, c2, c1), vC = sel(R, c1, c2);
-        const lmask pA = (F & h3 & ~f3) | (R & h0 & ~f0);
-        const lmask pB = (F & h2 & ~f2) | (R & h1 & ~f1);
-        const lmask pC = (F & h1 & ~f1) | (R & h2 & ~f2);
-        if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) {
-            if (__builtin_amdgcn_inverse_ballot_w64(pA)) stk_push_lds(stack, T, vA);
-            if (__builtin_amdgcn_inverse_ballot_w64(pB)) stk_push_lds(stack, T, vB);
-            if (__builtin_amdgcn_inverse_ballot_w64(pC)) stk_push_lds(stack, T, vC);
-            if (__builtin_amdgcn_inverse_ballot_w64(any)) T.cur = nxt;
-            else trav_pop_lds(T, stack);
-        } else {
-            if (__builtin_amdgcn_inverse_ballot_w64(pA)) stk_push(stack, T, vA);
-            if (__builtin_amdgcn_inverse_ballot_w64(pB)) stk_push(stack, T, vB);
-            if (__builtin_amdgcn_inverse_ballot_w64(pC)) stk_push(stack, T, vC);
-            if (__builtin_amdgcn_inverse_ballot_w64(any)) T.cur = nxt;
-            else trav_pop(T, stack);
-        }
-        return;
-    }
-#else
     RT_CHILD(k0, ub0)
     RT_CHILD(k1, ub1)
     RT_CHILD(k2, ub2)
     RT_CHILD(k3, ub3)
 #undef RT_CHILD
-#endif
-#endif // RT_WIDE_NODES
     // sorting network on (entry distance, child); misses carry +inf and sink to the end. One comparator = one compare into an
     // SGPR pair + four e64 selects on it (18 cycles).
 #define RT_CE(KA, CA, KB, CB)                                                        \
@@ -679,31 +395,9 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     RT_CE(k0, c0, k1, c1)
     RT_CE(k2, c2, k3, c3)
     RT_CE(k0, c0, k2, c2)
-#if RT_SORT_CE >= 4
-    RT_CE(k1, c1, k3, c3) // four comparators: k0 the minimum, k3 the maximum, k1 / k2 in either order
-#endif
-#if RT_SORT_CE >= 5
-    RT_CE(k1, c1, k2, c2)
-#endif
     // with fewer than five comparators the hits are no longer a sorted prefix of (k1, k2, k3): each is tested on its own below
 #undef RT_CE
-#if RT_POSTPONE
-    // the nearest hit child is a leaf and nothing is set aside yet: set it aside and go on with the next nearest entry
-    const bool hit0 = k0 < inf;
-    const bool aside = hit0 && (uint32_t)c0 > 0x80000000u && T.pend == kTravDone;
-    if (aside) T.pend = c0;
-    const bool descend = hit0 && !aside;
-#else
     const bool descend = k0 < inf;
-#endif
-#if RT_STATS_STALE
-    if (k3 < inf) stk_push_t(stack, T, c3, k3);
-    if (k2 < inf) stk_push_t(stack, T, c2, k2);
-    if (k1 < inf) stk_push_t(stack, T, c1, k1);
-    if (descend) T.cur = c0, T.cur_t = k0;
-    else trav_pop(T, stack);
-    return;
-#endif
     if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
         if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
         if (k2 < inf) stk_push_lds(stack, T, c2);
@@ -724,44 +418,11 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 // the wave's vote, so every extra leaf step costs it several iterations; the next record is fetched while the current
 // one is tested (two in flight, 24 VGPRs), the loop bound is the wave's largest leaf (uniform branch). Measured on the
 // megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
-template <bool BATCH, bool PF = false>
+template <bool BATCH>
 RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
-#if RT_POSTPONE
-    const bool from_pend = T.pend != kTravDone; // the postponed leaf first: it is the older (usually nearer) one
-    const uint32_t code = (uint32_t)~(from_pend ? T.pend : T.cur);
-#else
     const uint32_t code = (uint32_t)~T.cur;
-#endif
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
-#if RT_LEAF_UNROLL
-        // Unrolled by hand over two register sets (A, B) so that no record is ever copied: the rolled loop moved the prefetched
-        // record into the "current" registers every iteration, 25 v_mov_b64 = ~100 of the step's ~900 issue cycles. Every branch
-        // condition is wave-uniform (a ballot): the step runs as many tests as the largest leaf among its lanes.
-        const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
-#define RT_LOAD_TRI(K, A_, B_, C_) A_ = tri_ld4(p4 + (K) * kTriBytes), B_ = tri_ld4(p4 + (K) * kTriBytes + 16), C_ = tri_ld2(p4 + (K) * kTriBytes + 32)
-        float4 aA, bA, aB, bB;
-        float2 cA, cB;
-        RT_LOAD_TRI(0, aA, bA, cA);
-        const bool more1 = __ballot(rem >= 1u) != 0ull;
-        if (more1) {
-            aB = aA, bB = bA, cB = cA; // lanes without a triangle 1 re-read nothing: defined values, never tested
-            if (rem >= 1u) RT_LOAD_TRI(1, aB, bB, cB);
-        }
-        tri_test_regs<PF>(aA, bA, cA, T.o, T.d, T.best, S.shade, stack.pf_sink);
-        if (more1) {
-            const bool more2 = __ballot(rem >= 2u) != 0ull;
-            if (more2 && rem >= 2u) RT_LOAD_TRI(2, aA, bA, cA);
-            if (rem >= 1u) tri_test_regs<PF>(aB, bB, cB, T.o, T.d, T.best, S.shade, stack.pf_sink);
-            if (more2) {
-                const bool more3 = __ballot(rem >= 3u) != 0ull;
-                if (more3 && rem >= 3u) RT_LOAD_TRI(3, aB, bB, cB);
-                if (rem >= 2u) tri_test_regs<PF>(aA, bA, cA, T.o, T.d, T.best, S.shade, stack.pf_sink);
-                if (more3 && rem >= 3u) tri_test_regs<PF>(aB, bB, cB, T.o, T.d, T.best, S.shade, stack.pf_sink);
-            }
-        }
-#undef RT_LOAD_TRI
-#else
         const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
         float4 a = tri_ld4(p4), b = tri_ld4(p4 + 16);
         float2 c = tri_ld2(p4 + 32);
@@ -771,42 +432,16 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
             float4 na = a, nb = b;
             float2 nc = c;
             if (k <= rem) na = tri_ld4(p4 + k * kTriBytes), nb = tri_ld4(p4 + k * kTriBytes + 16), nc = tri_ld2(p4 + k * kTriBytes + 32);
-            if (k - 1u <= rem) tri_test_regs<PF>(a, b, c, T.o, T.d, T.best, S.shade, stack.pf_sink);
+            if (k - 1u <= rem) tri_test_regs(a, b, c, T.o, T.d, T.best);
             a = na, b = nb, c = nc;
         }
-        if (rem + 1u >= k) tri_test_regs<PF>(a, b, c, T.o, T.d, T.best, S.shade, stack.pf_sink); // triangle k-1, still untested where it exists
-#endif
-#if RT_POSTPONE
-        // the lane's own leaf is done: pop. The postponed one is done: if the lane also sits at a leaf, that one is set aside now
-        bool pop = true;
-        if (from_pend) {
-            pop = (uint32_t)T.cur > 0x80000000u;
-            T.pend = pop ? T.cur : kTravDone;
-        }
-        if (lanes(pop && !stack_shallow(stack, T, 0u)) == 0ull) {
-            if (pop) trav_pop_lds(T, stack);
-        } else if (pop) {
-            trav_pop(T, stack);
-        }
-#else
-#if RT_STATS_STALE
-        trav_pop(T, stack);
-#else
+        if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
         if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
         else trav_pop(T, stack);
-#endif
-#endif
     } else {
         tri_test(S.tris + (size_t)first * kTriBytes, T.o, T.d, T.best);
-#if RT_POSTPONE
-        const int32_t next = rem ? ~(int32_t)(((first + 1u) << 2) | (rem - 1u)) : kTravDone;
-        if (from_pend) T.pend = next;
-        else if (rem) T.cur = next;
-        else trav_pop(T, stack);
-#else
         if (rem) T.cur = ~(int32_t)(((first + 1u) << 2) | (rem - 1u));
         else trav_pop(T, stack);
-#endif
     }
 }
 
@@ -817,52 +452,20 @@ struct WaveStats {
 };
 
 // One wave-uniform step. Returns the number of lanes still traversing BEFORE the step (0 = all done).
-template <bool STATS = false, bool LEAF_BATCH = false, bool PF = false>
+template <bool STATS = false, bool LEAF_BATCH = false>
 RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg, WaveStats* ws = nullptr) {
     const bool inner = T.cur >= 0;
-#if RT_POSTPONE
-    const bool blocked = (uint32_t)T.cur > 0x80000000u; // at a leaf (negative, not kTravDone)
-    const bool leaf = blocked || T.pend != kTravDone;
-#if RT_PP_VOTE // leaf steps only when the lanes that cannot take an inner step outnumber those that can
-    const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(blocked));
-#else
-    const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
-#endif
-#else
     const bool leaf = T.cur < 0 && T.cur != kTravDone;
     const uint32_t ni = (uint32_t)__popcll(__ballot(inner)), nl = (uint32_t)__popcll(__ballot(leaf));
-#endif
-#ifndef RT_LEAF_MIN
-#define RT_LEAF_MIN 64u // with whole-leaf steps: leaf lanes that force a leaf step even against an inner majority
-#endif
-#ifndef RT_LEAF_BIAS_N
-#define RT_LEAF_BIAS_N 3u // the vote's weight: an inner step when ni * N >= nl * D. 1 / 1 is the plain majority of rounds 1-2; 3 / 4 takes a leaf step as soon as
-#define RT_LEAF_BIAS_D 4u // the leaf lanes exceed 3/4 of the inner lanes: a lane parked at a leaf is idle for as many iterations as the vote keeps going
-#endif                    // against it, and a leaf step that comes a little earlier with a few lanes less is cheaper than those idle lanes. Atrium 1080p 64 spp,
-                          // two runs each, megakernel / wavefront Mrays/s: 1/1 7220-7224 / 7185-7195; 5/8 7305-7321 / 7262; 2/3 7330-7338 / 7258-7267; 3/4 7305-7324 /
-                          // 7270-7276; 7/8 7309-7310 / 7254-7265 (8/4, 6/4: 6859, 6988)
-    if (ni * RT_LEAF_BIAS_N >= nl * RT_LEAF_BIAS_D && !(LEAF_BATCH && nl >= RT_LEAF_MIN)) {
-#if RT_STATS_STALE
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur_t > T.best.t));
-#elif RT_STATS_LEAFWAIT // diagnostic variant: the "top nodes" counter counts the lanes that sit at a leaf during an inner step instead
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += nl;
-#else
-        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * (RT_WIDE_NODES ? 128 : RT_NODE_OFFSETS ? 64 : 1)));
-#endif
+    // the vote, weighted 3 : 4 — a leaf step as soon as the leaf lanes exceed 3/4 of the inner lanes: a lane parked at a leaf is idle for as
+    // many iterations as the vote goes against it (plain majority: -1.2 %; EXPERIMENTS.md)
+    if (ni * 3u >= nl * 4u && !(LEAF_BATCH && nl >= 64u)) {
+        if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * 64));
         if (inner) trav_inner(S, T, stack, top, sg);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(__ballot(leaf));
-#if RT_STATS_STALE
-        if (STATS) ws->live_lane_steps += (uint32_t)__popcll(__ballot(leaf && T.cur_t > T.best.t));
-#endif
-        if (leaf) trav_leaf<LEAF_BATCH, PF>(S, T, stack);
+        if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
     }
-#if RT_POSTPONE
-    { // the stack ran dry while a leaf is set aside: it becomes the lane's current node (keeps cur == kTravDone <=> traversal complete)
-        const lmask dry = lanes(T.cur == kTravDone);
-        T.cur = sel(dry, T.cur, T.pend), T.pend = sel(dry, T.pend, kTravDone);
-    }
-#endif
     return ni + nl;
 }
 
@@ -909,17 +512,11 @@ RT_DEV float unorm8_to_float(uint32_t b) {
     return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
 }
 
-#ifndef RT_SHADE_NT
-#define RT_SHADE_NT 0 // experiment: shading records and texels fetched with the non-temporal hint (used once per hit; 18 + 9 MB that compete with nodes and triangles for the 4 MiB L2s)
-#endif
 // Texture::sample (src/material.hpp:45-53): constant colour, or nearest / repeat / normalised
 // fetch from layer tex_layer of the 512x512 RGBA8 array (sampler: src/render_wavefront.cpp:193-197)
 // ... in two halves, so that shading can issue the texel fetch (a miss into the Infinity Cache more often than not: 9 MB of texels,
 // nearest, used once) as soon as the hit's uv is known and interpolate / normalise / draw while it is in flight, instead of reaching
-// it at the end of Material::scatter's branch with nothing left to do but wait (round 3; RT_EARLY_TEXEL=0 restores the late fetch)
-#ifndef RT_EARLY_TEXEL
-#define RT_EARLY_TEXEL 1
-#endif
+// it at the end of Material::scatter's branch with nothing left to do but wait (round 3)
 RT_DEV bool albedo_is_texture(const MatRec& m) { return (m.type == RT_MAT_DIFFUSE || m.type == RT_MAT_METALLIC) && m.tex_kind != RT_TEX_COLOR; }
 RT_DEV uint32_t albedo_fetch(const SceneDev& S, const MatRec& m, float u, float v) { // caller: albedo_is_texture(m)
     float fu = u - __builtin_floorf(u);
@@ -941,13 +538,8 @@ RT_DEV f3 albedo(const SceneDev& S, const MatRec& m, float u, float v) {
     int iv = (int)__builtin_floorf(fv * 512.0f);
     iu = iu < 0 ? 0 : (iu > 511 ? 511 : iu);
     iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
-#if RT_SHADE_NT
-    const uint32_t texel = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(
-        S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u));
-#else
     const uint32_t texel = *reinterpret_cast<const uint32_t*>(
         S.tex + (((size_t)m.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u);
-#endif
     return mk3(unorm8_to_float(texel & 0xffu), unorm8_to_float((texel >> 8) & 0xffu), unorm8_to_float((texel >> 16) & 0xffu));
 }
 
@@ -1000,48 +592,17 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
         result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
         return true;
     }
-#if RT_SHADE_NT
-    const u32x4* sp = reinterpret_cast<const u32x4*>(S.shade + h.tri);
-    const u32x4 r0 = __builtin_nontemporal_load(sp), r1 = __builtin_nontemporal_load(sp + 1), r2 = __builtin_nontemporal_load(sp + 2), r3 = __builtin_nontemporal_load(sp + 3);
-    const float4 s0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-    const float4 s1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-    const float4 s2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-    const float4 s3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-#else
     const float4* sp = reinterpret_cast<const float4*>(S.shade + h.tri);
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-#endif
-#ifndef RT_SHADE_EARLY_D
-#define RT_SHADE_EARLY_D 1 // experiment: the incoming direction normalised while the shading record is in flight
-#endif
-#if RT_SHADE_EARLY_D
     const f3 d = normalize3(dir);
-#endif
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
-#ifndef RT_SHADE_RECORDS_UPFRONT
-#define RT_SHADE_RECORDS_UPFRONT 2 // bit 0: the instance record, bit 1: the material record
-#endif
-#if RT_SHADE_RECORDS_UPFRONT
     // The instance and material records are read WHOLE, here, as three 16-byte words each, and live in registers for the rest of the
     // round: one memory round trip after the shading record's, then one for the texel. Read field by field at their uses (round 2) they
     // became five more dependent fetches, each stuck behind a branch — the texture kind, the layer, the normal matrix after the first
     // normalisation, the emission, the roughness — and a shading round is made of waiting: ~21,000 wave cycles against ~600 instructions.
-#if RT_SHADE_RECORDS_UPFRONT & 1
-    InstRec inst;
-    {
-        const u32x4* ip = reinterpret_cast<const u32x4*>(S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw));
-        const u32x4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
-        inst.normal_mat[0] = __uint_as_float(i0.x), inst.normal_mat[1] = __uint_as_float(i0.y), inst.normal_mat[2] = __uint_as_float(i0.z);
-        inst.normal_mat[3] = __uint_as_float(i0.w), inst.normal_mat[4] = __uint_as_float(i1.x), inst.normal_mat[5] = __uint_as_float(i1.y);
-        inst.normal_mat[6] = __uint_as_float(i1.z), inst.normal_mat[7] = __uint_as_float(i1.w), inst.normal_mat[8] = __uint_as_float(i2.x);
-        inst.material = i2.y;
-    }
-#else
     const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
-#endif
-#if RT_SHADE_RECORDS_UPFRONT & 2
     MatRec mat;
     {
         const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + (S.packed_mat ? (iw >> kPackedInstBits) : inst.material));
@@ -1050,21 +611,12 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
         mat.color[2] = __uint_as_float(m1.x), mat.tex_layer = m1.y, mat.emissive[0] = __uint_as_float(m1.z), mat.emissive[1] = __uint_as_float(m1.w);
         mat.emissive[2] = __uint_as_float(m2.x), mat.roughness = __uint_as_float(m2.y), mat.ior = __uint_as_float(m2.z);
     }
-#else
-    const MatRec& mat = S.mats[S.packed_mat ? (iw >> kPackedInstBits) : inst.material];
-#endif
-#else
-    const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
-    const MatRec& mat = S.mats[S.packed_mat ? (iw >> kPackedInstBits) : inst.material];
-#endif
     const float bx = h.u, by = h.v;
     const float w = (1.0f - bx) - by;
     const float tu = (w * uv0x + bx * uv1x) + by * uv2x;
     const float tv = (w * uv0y + bx * uv1y) + by * uv2y;
-#if RT_EARLY_TEXEL
     uint32_t texel = 0;
     if (albedo_is_texture(mat)) texel = albedo_fetch(S, mat, tu, tv); // in flight during everything below
-#endif
     const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237 (here: its operands die early)
     rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
     const f3 vn = normalize3((w * n0 + bx * n1) + by * n2);
@@ -1072,15 +624,8 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
                      (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
     const f3 normal = normalize3(g);
-#if !RT_SHADE_EARLY_D
-    const f3 d = normalize3(dir);
-#endif
     f3 sdir, satt;
-#if RT_EARLY_TEXEL
     if (scatter<true>(S, mat, rng, d, normal, tu, tv, sdir, satt, texel)) {
-#else
-    if (scatter(S, mat, rng, d, normal, tu, tv, sdir, satt)) {
-#endif
         org = mk3(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
         dir = sdir;
         att = att * satt;

@@ -45,31 +45,6 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
 }
 
 // LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
-#if RT_SHADE_PREFETCH // the per-wave LDS sink of shade_prefetch (rt_device.h): 256 bytes per wave
-#define RT_PF_DECL(BLOCK) __shared__ uint32_t pf_sink_lds[(BLOCK)];
-#define RT_PF_SINK (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lds_i32*)((int32_t*)pf_sink_lds + (threadIdx.x & ~63u)))
-#else
-#define RT_PF_DECL(BLOCK)
-#define RT_PF_SINK 0u
-#endif
-#if RT_STATS_STALE
-#define RT_STALE_DECL float dstk_arr[kStackSize];
-#define RT_STALE_INIT , dstk_arr
-#else
-#define RT_STALE_DECL
-#define RT_STALE_INIT
-#endif
-#if RT_WIDE_NODES
-#define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
-    __shared__ u32x4 top_rec[kTopNodes * 8];                                                           \
-    __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
-    int32_t spill[kStackSize - kLdsStack];                                                             \
-    const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
-    top_tree_fill(S, top_rec, top_count);                                                              \
-    __syncthreads();                                                                                   \
-    const TopTree top{(uint32_t)(size_t)(lds_u32x4*)top_rec, top_count * 128};                         \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK), 0u};
-#else
 #define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
     __shared__ u32x4 top_all[4 * kTopNodes]; /* the four planes back to back: trav_inner's fetch addresses them from ONE base */ \
     u32x4 *const top_w0 = top_all, *const top_w1 = top_all + kTopNodes, *const top_w2 = top_all + 2 * kTopNodes, *const top_ch = top_all + 3 * kTopNodes; \
@@ -79,10 +54,7 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
     __syncthreads();                                                                                   \
     const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
-    RT_STALE_DECL                                                                                      \
-    RT_PF_DECL(BLOCK)                                                                                  \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK), RT_PF_SINK RT_STALE_INIT};
-#endif
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)};
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
@@ -135,17 +107,14 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 //             sample (new camera ray) or retire the pixel.
 // A lane therefore never idles while another lane finishes a long traversal or a long path; per-pixel
 // arithmetic and its order are unchanged (bit-exact with the per-pixel loops of the reference).
-// 6 waves/SIMD (80 VGPRs) measured best: 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
-#ifndef RT_MEGA_WAVES
-#define RT_MEGA_WAVES 6
-#endif
-#ifndef RT_MEGA_UNROLL
-#define RT_MEGA_UNROLL 3 // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
-#endif
-#ifndef RT_MEGA_REFILL
-#define RT_MEGA_REFILL 1u // idle lanes that trigger a pixel fetch (re-tuned with whole-leaf steps: 8 -> 1, +2 %)
-#endif
-// ... as the STARTING value. A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
+// Tuning constants of the persistent traversal kernels (k_megakernel, k_wf_finish). Each was swept on the atrium and the voxel terrain;
+// the sweeps are in EXPERIMENTS.md.
+constexpr uint32_t kMegaBlock = 512;   // threads per workgroup: 8 independent waves share one LDS copy of the top of the BVH
+constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compiled for (80 VGPRs): 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
+constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
+constexpr uint32_t kMegaShadePct = 75; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
+constexpr uint32_t kMegaRefill = 1;    // idle lanes that trigger a pixel fetch — as the STARTING value of RefillPolicy:
+// A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
 // part, and a lane that waits for company is idle: with lanes falling idle at a rate L per unit of wave time, refilling at T idle lanes
 // costs 64 * C * L / T + T / 2 lane-times per unit time (C: the wave time of a refill), least at T = sqrt(128 * C * L). L depends on the
 // workload — a pixel lives 64 spp x 8 rays x 26 steps on the atrium, 16 spp x 1.2 rays x 3 steps on the cube — so every wave estimates
@@ -154,75 +123,34 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 // (no clock, no float: a version with s_memtime and a float square root cost the atrium 2.5 %, the estimate from ended pixels alone
 // 1-2 %). Measured with fixed thresholds 1 / 4 / 8, Mrays/s: atrium 1080p 64 spp 7241 / 7153 / 6977, 16 spp 7086 / 7035 / 6871, 4 spp
 // 5580 / 6749 / 6618; Cornell box 4K 16 spp 9192 / 18106 / 18018; cube 4K 16 spp 21636 / 39292 / 50509.
-#ifndef RT_MEGA_REFILL_ADAPTIVE
-#define RT_MEGA_REFILL_ADAPTIVE 1
-#endif
 struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at the SGPR limit: four words of state cost it 0.9 %):
-    // bits 0-4 shading rounds of the window, 5-16 pixels ended, 17-27 traversal iterations (RT_MEGA_UNROLL steps each), 28-31 threshold - 1
-    uint32_t w = (RT_MEGA_REFILL - 1u) << 28;
+    // bits 0-4 shading rounds of the window, 5-16 pixels ended, 17-27 traversal iterations (kMegaUnroll steps each), 28-31 threshold - 1
+    uint32_t w = (kMegaRefill - 1u) << 28;
     RT_DEV uint32_t threshold() const { return (w >> 28) + 1u; }
-    RT_DEV void stepped() { // one iteration of the traversal loop (RT_MEGA_UNROLL steps)
-#if RT_MEGA_REFILL_ADAPTIVE
+    RT_DEV void stepped() { // one iteration of the traversal loop (kMegaUnroll steps)
         if (((w >> 17) & 0x7FFu) != 0x7FFu) w += 1u << 17; // saturates: a carry would drift into the threshold field (deep trees, slow tail waves)
-#endif
     }
     // after every shading round, in wave-uniform control flow; `finished`: this lane has just finished its pixel (or, where queue slots
     // are single paths, its path)
     RT_DEV void round(bool finished) {
-#if RT_MEGA_REFILL_ADAPTIVE
         w += ((uint32_t)__popcll(__ballot(finished)) << 5) + 1u;
         if ((w & 31u) == 0u) { // 32 rounds
             // (the round counter's carry out of bits 0-4 has just added one to the `ended` field: taken off again)
-            const uint32_t ended = ((w >> 5) & 0xFFFu) - 1u, steps = ((w >> 17) & 0x7FFu) * RT_MEGA_UNROLL;
+            const uint32_t ended = ((w >> 5) & 0xFFFu) - 1u, steps = ((w >> 17) & 0x7FFu) * kMegaUnroll;
             const uint32_t num = 320u * ended, den = 160u + steps;
             const uint32_t t = num < 4u * den ? 1u : num < 9u * den ? 2u : num < 16u * den ? 3u : num < 25u * den ? 4u : num < 36u * den ? 5u
                                : num < 64u * den ? 6u : num < 100u * den ? 8u : num < 144u * den ? 10u : num < 256u * den ? 12u : 16u;
             w = (t - 1u) << 28;
         }
-#else
-        (void)finished;
-#endif
     }
 };
-#ifndef RT_MEGA_SHADE_PCT
-#define RT_MEGA_SHADE_PCT 75u // shade when this share of the live lanes is waiting (re-tuned with whole-leaf steps: 50 -> 80, +3 %; round 3, with the 3/4
-                              // inner / leaf vote: 70 / 75 / 80 / 85 -> 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s megakernel, the wavefront renderer alike)
-#endif
-#ifndef RT_MEGA_TAIL_SHADE_PCT
-#define RT_MEGA_TAIL_SHADE_PCT RT_MEGA_SHADE_PCT // ... once the frame's pixel queue is drained (no refills to come)
-#endif
-#ifndef RT_MEGA_TAIL_UNROLL1
-#define RT_MEGA_TAIL_UNROLL1 0
-#endif
-#ifndef RT_MEGA_MISS_ROUND
-#define RT_MEGA_MISS_ROUND 0 // lanes waiting with a MISS that trigger a round of their own (experiment, measured: DESIGN.md §6); 0 = off
-#endif
-#ifndef RT_MEGA_LINGER
-#define RT_MEGA_LINGER 0 // experiment: traversal iterations a wave may add after the shading threshold is reached while a lane is on its last stack entry
-#endif
-#ifndef RT_MEGA_PRIO
-#define RT_MEGA_PRIO 2 // s_setprio per phase. 2 (default): waves in traversal issue before waves in a shading round: +6 %
-                       // (0 = no priorities, 1 = shading first: +4.5 %, 3 = a fixed priority per wave: +0 %, 4/5 = other levels: as 2)
-#endif
-#ifndef RT_MEGA_GSS
-#define RT_MEGA_GSS 0 // guided self-scheduling of the pixel queue (see the refill step): measured, off
-#endif
-#ifndef RT_MEGA_GSS_MIN
-#define RT_MEGA_GSS_MIN 1u // live lanes a wave may always hold
-#endif
-#ifndef RT_MEGA_BLOCK
-#define RT_MEGA_BLOCK 512 // 8 independent waves share one LDS copy of the top of the BVH
-#endif
 template <bool STATS>
-__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
                                                     unsigned long long* __restrict__ stats_out) {
     WaveStats ws;
-#if RT_MEGA_PRIO == 3
-    if ((threadIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(2); // the block's waves 4..7: the second wave on each SIMD
-#endif
     long long t_begin = 0, t_mark = 0, t_trav = 0, t_shade = 0;
     if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
     unsigned long long wall_begin = 0, wall_exhausted = 0;
@@ -236,14 +164,14 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     unsigned long long wave_rays = 0; // rays traced by this wave (wave-uniform: a scalar pair, no lane register, no reduction at the end)
     // the pixel's colour sum lives in LDS (three planes, one slot per lane): touched once per PATH, it would otherwise hold three of the 80
     // vector registers through every traversal step of a kernel that spills
-    __shared__ float color_lds[3 * RT_MEGA_BLOCK];
+    __shared__ float color_lds[3 * kMegaBlock];
     typedef __attribute__((address_space(3))) float lds_f32;
     lds_f32* const color_r = (lds_f32*)color_lds + threadIdx.x;
-    lds_f32* const color_g = color_r + RT_MEGA_BLOCK;
-    lds_f32* const color_b = color_g + RT_MEGA_BLOCK;
+    lds_f32* const color_g = color_r + kMegaBlock;
+    lds_f32* const color_b = color_g + kMegaBlock;
     RayState r{};
     Trav T;
-    RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
+    RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
     RefillPolicy refill;    // idle lanes that trigger a pixel fetch: set per wave from the pixels it finishes
@@ -254,20 +182,11 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     // issue, what matters is that all waves advance over ONE front and the frame's last pixels are not all in the region that happened
     // to be slowest: one frame-wide cursor, atrium 1080p 16 spp 38.72 -> 37.83 ms, Cornell box 1024x1024 64 spp 29.8 -> 25.2 ms
     // (its regions differ a lot in cost: ceiling and light, walls, floor).
-#ifndef RT_MEGA_XCD_REGIONS
-#define RT_MEGA_XCD_REGIONS 0
-#endif
-#if RT_MEGA_XCD_REGIONS
-    const uint32_t region_slots = ((n_slots + 7u) / 8u + 63u) & ~63u;
-    uint32_t region = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID[3:0]
-    uint32_t regions_done = 0;
-#else
     const uint32_t region_slots = (n_slots + 63u) & ~63u; // one region: the frame
     uint32_t region = 0;
     uint32_t regions_done = 7;
-#endif
     const uint32_t region_left = region_slots;                                                  // slots of one region
-    const uint32_t waves_per_region = (gridDim.x * (RT_MEGA_BLOCK / 64u) + 7u) / 8u;           // the waves that start on it
+    const uint32_t waves_per_region = (gridDim.x * (kMegaBlock / 64u) + 7u) / 8u;           // the waves that start on it
     uint32_t last_base = 0; // cursor of the current region as this wave last saw it
     (void)region_left, (void)waves_per_region, (void)last_base; // only read with RT_MEGA_GSS
     auto start_pixel = [&](uint32_t p) { // pixel slot p (8x8-tile order) becomes this lane's pixel; slots outside the image are skipped
@@ -290,9 +209,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
     // pixels. 1/8 of the 1080p atrium frame, 64 spp: 32.9 -> 29.6 ms. (Spreading the slots of the dynamic regime the same way changes
     // nothing on 1/2 and 1/4 of the frame: there idle lanes refill, and the tail is a single chain.)
     {
-        const uint32_t n_waves = gridDim.x * (RT_MEGA_BLOCK / 64u);
+        const uint32_t n_waves = gridDim.x * (kMegaBlock / 64u);
         if (n_slots <= n_waves * 64u) {
-            const uint32_t p = (uint32_t)lane * n_waves + blockIdx.x * (RT_MEGA_BLOCK / 64u) + (threadIdx.x >> 6);
+            const uint32_t p = (uint32_t)lane * n_waves + blockIdx.x * (kMegaBlock / 64u) + (threadIdx.x >> 6);
             if (p < n_slots) start_pixel(p);
             exhausted = true;
             if (STATS) wall_exhausted = wall_clock64();
@@ -308,19 +227,11 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             // RT_MEGA_GSS=1 (experiment, OFF): guided self-scheduling of the pixel queue — a wave may hold at most remaining pixels /
             // waves live lanes, so that the last pixels of the queue (and all pixels of a small tile) are spread thinly over ALL
             // waves instead of filling a few of them. The idea was that a pixel's chain runs faster in a wave with few live lanes.
-            // It does not: a lane whose traversal is complete still waits for RT_MEGA_SHADE_PCT of its wave, so the chain is paced
+            // It does not: a lane whose traversal is complete still waits for kMegaShadePct of its wave, so the chain is paced
             // by the slowest lanes whatever their number. Measured (64 spp, 1080p atrium): full frame 153 -> 210 ms (the last fifth
             // of every region runs in under-filled waves), 1/8 tile 34.1 -> 32.1 ms, 1/16 tile 28.6 -> 29.0 ms. Scheduling only:
             // every pixel is computed exactly as before.
             uint32_t take = cnt;
-#if RT_MEGA_GSS
-            {
-                const uint32_t remaining = region_left > last_base ? region_left - last_base : 0u; // as of this wave's last fetch
-                const uint32_t quota = remaining / waves_per_region + RT_MEGA_GSS_MIN;
-                const uint32_t n_now = 64u - cnt;
-                take = quota > n_now ? (quota - n_now < cnt ? quota - n_now : cnt) : 0u;
-            }
-#endif
             if (cnt >= refill.threshold() && take) {
                 // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
                 uint32_t base = 0;
@@ -353,33 +264,16 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         (void)lingered;
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? RT_MEGA_TAIL_SHADE_PCT : RT_MEGA_SHADE_PCT)) {
-#if RT_MEGA_LINGER
-                // the threshold is reached, but a lane on its LAST stack entry is about to finish: a round that starts now makes it wait for
-                // the whole next cycle; a few more steps take it along (at most RT_MEGA_LINGER more iterations, never beyond 90 % waiting)
-                const bool soon = live && !waiting && T.sp == stack.base;
-                if (lingered >= RT_MEGA_LINGER || __ballot(soon) == 0ull || (uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * 90u) break;
-                ++lingered;
-#else
-                break;
-#endif
-            }
-#if RT_MEGA_MISS_ROUND
-            if ((uint32_t)__popcll(__ballot(waiting && T.best.tri == kNoTri)) >= RT_MEGA_MISS_ROUND) {
-                miss_round = true;
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? kMegaShadePct : kMegaShadePct)) {
                 break;
             }
-#endif
-            if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
+            if (STATS) ws.live_lane_steps += n_live;
             refill.stepped();
-            (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
-#if RT_MEGA_TAIL_UNROLL1
-            if (exhausted) continue; // drained queue: latency matters more than the two saved exit checks
-#endif
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < RT_MEGA_UNROLL; ++k) { // the exit tests are checked every RT_MEGA_UNROLL steps
-                if (STATS && !RT_STATS_STALE) ws.live_lane_steps += n_live;
-                (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
+            for (int k = 1; k < kMegaUnroll; ++k) { // the exit tests are checked every kMegaUnroll steps
+                if (STATS) ws.live_lane_steps += n_live;
+                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
@@ -388,42 +282,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
             t_trav += now - t_mark, t_mark = now;
         }
         // SHADE the lanes whose traversal is complete
-#if RT_MEGA_PRIO == 1
-        __builtin_amdgcn_s_setprio(2);
-#elif RT_MEGA_PRIO == 2 || RT_MEGA_PRIO == 4 || RT_MEGA_PRIO == 5
         __builtin_amdgcn_s_setprio(0);
-#endif
         bool pixel_finished = false;
         if (!miss_round) wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
-#if RT_MEGA_MISS_ROUND
-        // VERDICT r2 item 5, an experiment (default off): a cheap step kind for the paths that END WITHOUT A SCATTER — a ray that missed
-        // adds att * (sky + rad) (shade_hit's miss branch, src/trace_ray.hpp:25-27), its pixel takes its next camera ray or retires —
-        // fired as soon as RT_MEGA_MISS_ROUND lanes wait with a miss, instead of waiting for RT_MEGA_SHADE_PCT of the wave. Per pixel the
-        // operations and their order are those of the full round (the re-packing of an unchanged ray state is the identity).
-        if (miss_round) {
-            wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && T.best.tri == kNoTri));
-            if (live && T.cur == kTravDone && T.best.tri == kNoTri) {
-                const f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2])), rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-                const f3 add = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
-                *color_r = *color_r + add.x, *color_g = *color_g + add.y, *color_b = *color_b + add.z;
-                s++;
-                depth = 0;
-                if (s < spp) {
-                    r = camera_ray(cam, x, gy, rng);
-                    trav_begin(T, r.org, ray_dir(r), stack);
-                } else {
-                    live = false, pixel_finished = true;
-                    const float n = (float)spp;
-                    const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
-                    const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
-                    if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
-                    if (out_u8)
-                        reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
-                                                                 ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
-                }
-            }
-        } else
-#endif
         if (live && T.cur == kTravDone) {
             f3 res;
             const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
@@ -451,15 +312,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_megakernel(Sce
         }
         refill.round(pixel_finished);
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
-#if RT_MEGA_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#elif RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(2);
-#elif RT_MEGA_PRIO == 4
-        __builtin_amdgcn_s_setprio(3);
-#elif RT_MEGA_PRIO == 5
-        __builtin_amdgcn_s_setprio(1);
-#endif
     }
     if (lane == 0 && wave_rays) atomicAdd(ray_counter, wave_rays);
     if (STATS && lane == 0) {
@@ -570,45 +423,22 @@ __global__ void __launch_bounds__(1024) k_wf_order_tiles(const uint32_t* __restr
 // (one atomic per chunk), keeps its 64 lanes fed from the chunk, and writes (t, u, v, tri) to hits[slot].
 // Inside the loop only three uniform step kinds exist: inner node, one triangle, or refill
 // (store finished hits + load new rays) when at least kExtendRefill lanes ask for it.
-#ifndef RT_EXTEND_CHUNK
-#define RT_EXTEND_CHUNK 128
-#endif
-#ifndef RT_EXTEND_UNROLL
-#define RT_EXTEND_UNROLL 1
-#endif
-#ifndef RT_EXTEND_PRIO
-#define RT_EXTEND_PRIO 0
-#endif
-#ifndef RT_EXTEND_REFILL
-#define RT_EXTEND_REFILL 16
-#endif
-constexpr uint32_t kExtendChunk = RT_EXTEND_CHUNK;
-constexpr uint32_t kExtendRefill = RT_EXTEND_REFILL;
-#ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 8
-#endif
-#ifndef RT_EXTEND_BLOCK
-#define RT_EXTEND_BLOCK 1024
-#endif
-#ifndef RT_EXTEND_LEAF_BATCH
-#define RT_EXTEND_LEAF_BATCH true // whole-leaf steps as in the megakernel (~24 more VGPRs than one triangle per step: they fit in EXTEND's 64
-                                  // since SLP packing is off; round 1: spills, -25 %; now +6 % on the wavefront frame)
-#endif
+constexpr uint32_t kExtendChunk = 128;  // queue slots a wave claims per cursor atomic
+constexpr uint32_t kExtendRefill = 16;  // idle lanes that trigger a refill from the wave's chunk
+constexpr uint32_t kExtendBlock = 1024; // 16 independent waves per workgroup
+constexpr uint32_t kExtendWaves = 8;    // waves per SIMD (64 VGPRs): EXTEND is occupancy-sensitive (8 -> 6: -19 %)
 template <bool STATS>
-__global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(SceneDev S, QueueDev qin, float4* __restrict__ hits,
+__global__ void __launch_bounds__(kExtendBlock, kExtendWaves) k_wf_extend(SceneDev S, QueueDev qin, float4* __restrict__ hits,
                                                                     const uint32_t* __restrict__ count_in,
                                                                     uint32_t* __restrict__ cursor,
                                                                     unsigned long long* __restrict__ stats_out) {
-#if RT_EXTEND_PRIO
-    __builtin_amdgcn_s_setprio(RT_EXTEND_PRIO); // against the other stream's SHADE waves on the same SIMD
-#endif
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
-    constexpr uint32_t kWavesPerBlock = RT_EXTEND_BLOCK / 64;
+    constexpr uint32_t kWavesPerBlock = kExtendBlock / 64;
     const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); // waves of a block are independent
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    RT_TRAVERSAL_LDS(RT_EXTEND_BLOCK)
+    RT_TRAVERSAL_LDS(kExtendBlock)
     Trav T;
     T.cur = kTravDone;
     bool has = false;     // this lane holds a ray whose hit has not been written yet
@@ -675,12 +505,7 @@ __global__ void __launch_bounds__(RT_EXTEND_BLOCK, RT_EXTEND_WAVES) k_wf_extend(
             continue;
         }
         if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-        (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, sg, &ws);
-#pragma unroll
-        for (int k = 1; k < RT_EXTEND_UNROLL; ++k) { // refill is looked at every RT_EXTEND_UNROLL steps
-            if (STATS) ws.live_lane_steps += (uint32_t)__popcll(__ballot(has));
-            (void)trav_step_wave<STATS, RT_EXTEND_LEAF_BATCH>(S, T, stack, top, sg, &ws);
-        }
+        (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
     }
     if (STATS && lane == 0) {
         atomicAdd(stats_out + 0, (unsigned long long)ws.inner_steps), atomicAdd(stats_out + 1, (unsigned long long)ws.inner_lanes);
@@ -876,22 +701,7 @@ struct FinishRequeue {
 constexpr uint32_t kRqIdleCap = 1u << 26;
 constexpr uint32_t kOutBlock = 256u;   // SHOOT: slots of the next queue a workgroup reserves per device atomic
 constexpr uint32_t kNoRay = 0xFFFFFFFFu; // pixel id of a hole in a SHOOT-produced queue
-#ifndef RT_RQ_STAGE
-#define RT_RQ_STAGE 96u
-#endif
-#ifndef RT_RQ_FLUSH
-#define RT_RQ_FLUSH 32u
-#endif
-#ifndef RT_RQ_CLAIM
-#define RT_RQ_CLAIM 16u
-#endif
-#ifndef RT_RQ_IDLE_SLEEP
-#define RT_RQ_IDLE_SLEEP 8
-#endif
-#ifndef RT_RQ_STALE
-#define RT_RQ_STALE 4u // shading rounds an entry may wait in a busy wave's stage
-#endif
-constexpr uint32_t kRqEmpty = 0xFFFFFFFFu, kRqStage = RT_RQ_STAGE, kRqFlush = RT_RQ_FLUSH, kRqClaim = RT_RQ_CLAIM;
+constexpr uint32_t kRqEmpty = 0xFFFFFFFFu, kRqStage = 96u, kRqFlush = 32u, kRqClaim = 16u;
 static_assert(kRqFlush + 64u <= kRqStage, "a whole wave of new entries must fit behind an unflushed stage");
 RT_DEV unsigned long long rq_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RT_DEV void rq_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -902,7 +712,7 @@ RT_DEV void rq_store64(unsigned long long* p, unsigned long long v) { __hip_atom
 // (src/render_wavefront.cpp:244-312: intersect, shade, compact, one kernel). With bounce_limit = 1 this is the reference's schedule as
 // ONE launch per bounce: no hit-record round trip (EXTEND -> SHADE costs 32 B per ray) and half the launches of the split pipeline.
 template <bool STATS, bool REQ, bool LIMIT = false>
-__global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
+__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
                                                                     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
                                                                     unsigned long long* __restrict__ extra_rays, uint32_t first_depth, uint32_t max_depth,
@@ -927,10 +737,10 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     WaveStats ws;
     const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
-    constexpr uint32_t kWavesPerBlock = RT_MEGA_BLOCK / 64;
+    constexpr uint32_t kWavesPerBlock = kMegaBlock / 64;
     const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    RT_TRAVERSAL_LDS(RT_MEGA_BLOCK)
+    RT_TRAVERSAL_LDS(kMegaBlock)
     __shared__ unsigned long long rq_stage_mem[REQ ? kWavesPerBlock * kRqStage : 1u];
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
     lds_u64_t* stage = (lds_u64_t*)rq_stage_mem + (threadIdx.x >> 6) * kRqStage; // REQ: this wave's staged entries
@@ -942,7 +752,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
     // global row were four integer divisions per SAMPLE (id % width, id / width, and the two of tile_global_row: ~100 instructions of a
     // ~600-instruction shading round that nearly always holds a lane starting a sample); they are now taken once per PIXEL and kept,
     // packed, in one LDS word per lane (images of up to 65,535 x 65,535; larger ones divide as before).
-    __shared__ uint32_t xg_lds[RT_MEGA_BLOCK];
+    __shared__ uint32_t xg_lds[kMegaBlock];
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + threadIdx.x;
     const bool xg_packed = camp->width < 65536 && camp->height < 65536;
@@ -1102,7 +912,7 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
                     if (lane == 0) __hip_atomic_store(fq.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(RT_RQ_IDLE_SLEEP); // a wave with nothing to trace must not take issue cycles from those that have
+                __builtin_amdgcn_s_sleep(8); // a wave with nothing to trace must not take issue cycles from those that have
                 continue;
             }
             if (drained) break;
@@ -1110,19 +920,17 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
         }
         idle_polls = 0;
         const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
-        for (;;) { // TRAVERSE until RT_MEGA_SHADE_PCT of the live lanes wait for shading
+        for (;;) { // TRAVERSE until kMegaShadePct of the live lanes wait for shading
             const bool done_trav = live && T.cur == kTravDone;
-            if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * RT_MEGA_SHADE_PCT) break;
-            if (STATS) ws.live_lane_steps += n_live * RT_MEGA_UNROLL;
+            if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * kMegaShadePct) break;
+            if (STATS) ws.live_lane_steps += n_live * kMegaUnroll;
             refill.stepped();
-            (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < RT_MEGA_UNROLL; ++k) (void)trav_step_wave<STATS, true, true>(S, T, stack, top, sg, &ws);
+            for (int k = 1; k < kMegaUnroll; ++k) (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
         }
         if (STATS) ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
-#if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
-#endif
         bool requeue = false, slot_finished = false, hand_on = false;
         // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes): every other ray counts here
         wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth)));
@@ -1229,11 +1037,9 @@ __global__ void __launch_bounds__(RT_MEGA_BLOCK, RT_MEGA_WAVES) k_wf_finish(Scen
             // append when there is enough to amortise the ticket — or at once when a lane of this wave starves (work is scarce: pass it on),
             // and in any case after a few rounds, so that no pixel waits long in a busy wave's stage
             stale = staged ? stale + 1u : 0u;
-            if (staged >= kRqFlush || (staged && (wait_m != 0ull || stale >= RT_RQ_STALE))) flush(), stale = 0;
+            if (staged >= kRqFlush || (staged && (wait_m != 0ull || stale >= 4u))) flush(), stale = 0;
         }
-#if RT_MEGA_PRIO == 2
         __builtin_amdgcn_s_setprio(2);
-#endif
     }
     if (lane == 0 && wave_rays) atomicAdd(extra_rays, wave_rays);
     if (STATS && lane == 0) {

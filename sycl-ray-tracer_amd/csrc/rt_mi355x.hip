@@ -18,14 +18,6 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
-// RT_WITH_TS=1 (the experiment library librt_exp_ts.so only, never the product): k_megakernel_ts, traversal and shading waves decoupled
-// through LDS slot queues (rt_kernel_ts.h; measured 4.1 against 7.05 Grays/s), selected at run time with RT_MEGA_TS=1
-#ifndef RT_WITH_TS
-#define RT_WITH_TS 0
-#endif
-#if RT_WITH_TS
-#include "rt_kernel_ts.h"
-#endif
 #include "scene_build.h"
 
 using namespace rt;
@@ -35,9 +27,6 @@ using namespace rt;
 // everything in k_wf_finish (one compacted queue per sample: generate -> queue -> persistent waves) 5282 when each of the two
 // overlapping launches asks for all 6 wave slots per SIMD, 6086 when each asks for its half. BASELINE config 5's tile (4K, depth 16):
 // 56.8 ms -> 39.2 ms against the megakernel's 30.9. Default: 0 bounces launch by launch.
-#ifndef RT_WF_FINISH_DEPTH_DEFAULT
-#define RT_WF_FINISH_DEPTH_DEFAULT 0u
-#endif
 // Samples k_wf_finish renders per pixel and launch (RT_WF_SAMPLES_PER_LAUNCH). 0, the default, is the ONE-LAUNCH schedule: all samples in
 // one launch per frame and tile on one stream lane, the lane keeps its pixel (depth first) and a wave takes exactly as many queue slots as
 // it has idle lanes — the megakernel's loop fed from a queue, and as fast: atrium 1080p 64 spp 151.7 ms (megakernel 149.8), 1/2 / 1/4 /
@@ -52,9 +41,6 @@ using namespace rt;
 //    it wins over a launch per sample on small tiles and deep paths (config 5's tile 629 -> 495 ms; 1080p depth 50: 5708 -> 6486 Mrays/s);
 //  - C > 1, depth first on two stream lanes (RT_WF_REQUEUE=0): 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s for C = 1 / 2 / 4 / 8 / 16 at 1080p
 //    16 spp when waves took private 128-slot chunks (whole pixel-chains: the launch ended with a few waves working through theirs).
-#ifndef RT_WF_SAMPLES_PER_LAUNCH_DEFAULT
-#define RT_WF_SAMPLES_PER_LAUNCH_DEFAULT 0u
-#endif
 
 namespace {
 
@@ -202,8 +188,8 @@ struct rt_renderer {
     //   their paths; >= max_depth = the reference's schedule (a launch pair per bounce).
     //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
     //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
-    rt_schedule sched{RT_WF_FINISH_DEPTH_DEFAULT, RT_WF_SAMPLES_PER_LAUNCH_DEFAULT, 0u, -1, 0u, 0u, -1, 0u, 0u};
-    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = RT_MEGA_WAVES / stream lanes (RT_WF_FINISH_OCC, tuning)
+    rt_schedule sched{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u};
+    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = kMegaWaves / stream lanes (RT_WF_FINISH_OCC, tuning)
     // SHOOT's input claims (round 3). A device atomic on the queue cursor serialises (~6 ns each, more under contention): with 128-slot
     // claims a 2 M-ray launch made 16 k of them, and smaller claims were far worse (64 slots: 4.7 -> 3.8 Grays/s, 32: 2.3). Now 85 % of
     // the queue is handed out STATICALLY in equal parts (whole 64-slot generations per wave) and only the rest goes through the cursor,
@@ -228,13 +214,7 @@ struct rt_renderer {
     std::vector<hipEvent_t> ev_pool;
     // diagnostics (scripts/occupancy_probe.py): RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
-    uint32_t mega_lds_pad = 0, mega_occ = RT_MEGA_WAVES;
-    // RT_MEGA_TS=1: k_megakernel_ts (traversal and shading decoupled inside every workgroup, rt_kernel_ts.h) instead of k_megakernel
-    bool mega_ts = false;
-#if RT_WITH_TS
-    TsSlots ts_slots{};
-    uint32_t ts_blocks = 0;
-#endif
+    uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
 };
 
 namespace {
@@ -251,9 +231,6 @@ void free_tile_buffers(rt_renderer* r) {
         p = nullptr;
     };
     fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
-#if RT_WITH_TS
-    fr(r->ts_slots.org_px), fr(r->ts_slots.state), fr(r->ts_slots.misc), fr(r->ts_slots.color_s), fr(r->ts_slots.hit);
-#endif
     for (auto& L : r->lanes) {
         fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra), fr(L.d_cost), fr(L.d_tile_key), fr(L.d_tile_order);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
@@ -320,7 +297,7 @@ uint32_t wf_stream_lanes(const rt_renderer* r) {
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
 bool wf_spread(const rt_renderer* r) {
-    return wf_one_launch(r) && wf_stream_lanes(r) == 1 && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+    return wf_one_launch(r) && wf_stream_lanes(r) == 1 && (uint64_t)r->n_local <= (uint64_t)r->n_cus * 4u * kMegaWaves * 64u;
 }
 bool wf_uses_requeue(const rt_renderer* r) { return r->sched.requeue != 0 && !wf_one_launch(r); }
 // Longest chains first (rt_kernels.h, k_wf_order_tiles): in the one-launch schedule, for tiles of more than one pixel generation, sample 0
@@ -332,7 +309,7 @@ bool wf_uses_requeue(const rt_renderer* r) { return r->sched.requeue != 0 && !wf
 bool wf_cost_order(const rt_renderer* r) {
     if (r->sched.cost_order == 0 || !wf_one_launch(r) || wf_stream_lanes(r) != 1) return false;
     if (r->sched.cost_order > 0) return true;
-    return !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * RT_MEGA_WAVES * 64u;
+    return !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * kMegaWaves * 64u;
 }
 
 // samples one k_wf_finish launch renders per pixel (1 = a launch per sample). More than one only when k_wf_finish takes over from the
@@ -369,18 +346,6 @@ int alloc_tile_buffers(rt_renderer* r) {
     HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors + error word
-#if RT_WITH_TS
-        if (r->mega_ts) {
-            const uint32_t tiles = (uint32_t)((r->width + 7) / 8) * (uint32_t)((r->tile.local_rows + 7) / 8);
-            r->ts_blocks = std::max<uint32_t>(1u, std::min<uint32_t>((tiles + 7u) / 8u, (uint32_t)r->n_cus * 3u)); // three workgroups per CU
-            const size_t ns = (size_t)r->ts_blocks * RT_TS_SLOTS;
-            HIPCHK(hipMalloc((void**)&r->ts_slots.org_px, ns * 16));
-            HIPCHK(hipMalloc((void**)&r->ts_slots.state, ns * 16));
-            HIPCHK(hipMalloc((void**)&r->ts_slots.misc, ns * 8));
-            HIPCHK(hipMalloc((void**)&r->ts_slots.color_s, ns * 16));
-            HIPCHK(hipMalloc((void**)&r->ts_slots.hit, ns * 16));
-        }
-#endif
     } else {
         const uint32_t K = wf_stream_lanes(r);
         const bool per_bounce = r->sched.finish_depth > 0 && r->max_depth > 0; // EXTEND + SHADE launch pairs: the second queue and the hit records
@@ -393,7 +358,7 @@ int alloc_tile_buffers(rt_renderer* r) {
             L.n_local = (uint32_t)L.tile.local_rows * (uint32_t)r->width;
             const size_t m = std::max<size_t>(L.n_local, 1);
             // SHOOT launches reserve the next queue in blocks of kOutBlock slots per workgroup: up to one partly used block per workgroup
-            const size_t mq = m + (per_bounce && r->sched.fused_bounce ? (size_t)kOutBlock * ((size_t)r->n_cus * 4u * RT_MEGA_WAVES / (RT_MEGA_BLOCK / 64) + 1u) : 0u);
+            const size_t mq = m + (per_bounce && r->sched.fused_bounce ? (size_t)kOutBlock * ((size_t)r->n_cus * 4u * kMegaWaves / (kMegaBlock / 64) + 1u) : 0u);
             for (int qi = 0; qi < (per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
                 auto& q = L.q[qi];
                 HIPCHK(hipMalloc((void**)&q.org_id, mq * 16));
@@ -461,7 +426,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     const uint32_t K = (uint32_t)r->lanes.size();
     // one stream lane (the default schedule): its launches go straight onto `st` — no fork / join events, no second stream to wake up
     auto lane_stream = [&](rt_renderer::WfLane& L) { return K == 1 ? st : L.stream; };
-    constexpr uint32_t ext_wpb = RT_EXTEND_BLOCK / 64;
+    constexpr uint32_t ext_wpb = kExtendBlock / 64;
     std::vector<uint32_t> grid(K), ext_grid(K), buf(K, 0u);
     std::vector<size_t> ne(K, 0);
     for (uint32_t k = 0; k < K; ++k) {
@@ -473,7 +438,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         grid[k] = (L.n_local + 255u) / 256u;
         // persistent EXTEND waves: fill every SIMD at the kernel's occupancy, never more than there are chunks
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
-                                                                            (uint32_t)r->n_cus * 4u * RT_EXTEND_WAVES));
+                                                                            (uint32_t)r->n_cus * 4u * kExtendWaves));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
         HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L)));
         HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L)));
@@ -514,8 +479,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 uint32_t* counts = L.d_counts + (size_t)s * (D + 1);
                 uint32_t* cursors = L.d_counts + L.h_counts.size();
                 if (r->sched.fused_bounce) { // SHOOT: intersect + shade + compact in ONE launch per bounce (k_wf_finish<.., LIMIT> with a limit of one bounce)
-                    constexpr uint32_t fin_wpb = RT_MEGA_BLOCK / 64;
-                    const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
+                    constexpr uint32_t fin_wpb = kMegaBlock / 64;
+                    const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, kMegaWaves / K));
                     const uint32_t chunk_slots = r->wf_shoot_chunk ? r->wf_shoot_chunk : r->wf_shoot_tail ? 256u : (L.n_local < 2u * 64u * fin_cap ? 64u : kExtendChunk);
                     const uint32_t first_slots = r->wf_shoot_tail ? 64u : chunk_slots; // (guided: the kernel sizes the static part from the queue's length; 64 = at least)
                     const uint32_t fin_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + first_slots - 1u) / first_slots, fin_cap));
@@ -529,7 +494,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     }
                     const FinishRequeue no_fq{nullptr, nullptr, reinterpret_cast<uint32_t*>(L.d_extra + r->spp), 0u}; // only the error word
 #define RT_SHOOT_LAUNCH(ST)                                                                                                                  \
-    hipLaunchKernelGGL((k_wf_finish<ST, false, true>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + d,    \
+    hipLaunchKernelGGL((k_wf_finish<ST, false, true>), dim3(fin_grid), dim3(kMegaBlock), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + d,    \
                        cursors + (size_t)s * D + d, L.d_rng, L.d_accum, L.d_extra + s, d, D, 1u, r->rr_start,                                 \
                        ST ? r->d_stats : (unsigned long long*)nullptr, no_fq, chunk_arg, (uint8_t*)nullptr, L.q[buf[k] ^ 1], counts + d + 1, 1u, 1u)
                     if (r->d_stats) RT_SHOOT_LAUNCH(true);
@@ -551,10 +516,10 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     HIPCHK(hipEventRecord(e0, ls));
                 }
                 if (r->d_stats)
-                    hipLaunchKernelGGL(k_wf_extend<true>, dim3(ext_grid[k]), dim3(RT_EXTEND_BLOCK), 0, ls, S, L.q[buf[k]], L.d_hits,
+                    hipLaunchKernelGGL(k_wf_extend<true>, dim3(ext_grid[k]), dim3(kExtendBlock), 0, ls, S, L.q[buf[k]], L.d_hits,
                                        counts + d, cursors + (size_t)s * D + d, r->d_stats);
                 else
-                    hipLaunchKernelGGL(k_wf_extend<false>, dim3(ext_grid[k]), dim3(RT_EXTEND_BLOCK), 0, ls, S, L.q[buf[k]], L.d_hits,
+                    hipLaunchKernelGGL(k_wf_extend<false>, dim3(ext_grid[k]), dim3(kExtendBlock), 0, ls, S, L.q[buf[k]], L.d_hits,
                                        counts + d, cursors + (size_t)s * D + d, (unsigned long long*)nullptr);
                 if (r->profile_kernels) HIPCHK(hipEventRecord(e1, ls));
                 {
@@ -581,7 +546,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
             }
         }
         if (D0 < D) {
-            constexpr uint32_t fin_wpb = RT_MEGA_BLOCK / 64;
+            constexpr uint32_t fin_wpb = kMegaBlock / 64;
             for (uint32_t k = 0; k < K; ++k) {
                 auto& L = r->lanes[k];
                 if (L.n_local == 0) continue;
@@ -591,7 +556,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 // persistent grid: wf_finish_occ waves per SIMD for THIS launch. The lanes' launches overlap on the device, so each asks for
                 // its share of the SIMDs' wave slots rather than all of them: fewer, longer-lived waves follow more paths per lane
                 // (less idling at the end of each wave's last paths) and the streams' kernels are resident side by side.
-                const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, RT_MEGA_WAVES / K));
+                const uint32_t fin_cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : std::max<uint32_t>(1u, kMegaWaves / K));
                 // queue slots a wave takes at a time: 128 as EXTEND does — but 64 (one per lane) when that is what it takes to give every
                 // resident wave something to do (a 1/8 tile has fewer pixels than the chip has lanes)
                 const uint32_t chunk_slots = (L.n_local < 2u * 64u * fin_cap || (n_samples > 1 && !L.d_rq_entries)) ? 64u : kExtendChunk;
@@ -612,7 +577,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                     HIPCHK(hipMemsetAsync(L.d_rq_ctl, 0, 80 * 4, ls));
                 }
 #define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
-    hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(RT_MEGA_BLOCK), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
+    hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(kMegaBlock), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
                        cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
                        ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots, lpt && s == 0 ? L.d_cost : (uint8_t*)nullptr, QueueDev{}, (uint32_t*)nullptr, 0u,     \
                        shoot_frame ? 1u : 0u)
@@ -669,7 +634,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 8 * sizeof(unsigned long long), st)); // ray count + region cursors
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
-        constexpr uint32_t mega_wpb = RT_MEGA_BLOCK / 64;
+        constexpr uint32_t mega_wpb = kMegaBlock / 64;
         // (in the chain regime — fewer tiles than wave slots — 64 pixels on 4,050 waves beat 42 pixels on all 6,144: 29.5 against 33.7 ms)
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
@@ -683,25 +648,14 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         HIPCHK(hipEventRecord(e0, st));
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
-#if RT_WITH_TS
-        } else if (r->mega_ts) {
-            if (r->d_stats) {
-                HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
-                hipLaunchKernelGGL(k_megakernel_ts<true>, dim3(r->ts_blocks), dim3(kTsBlock), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode,
-                                   r->rr_start, d_f32, d_u8, r->d_ray_counter, r->ts_slots, r->d_stats);
-            } else {
-                hipLaunchKernelGGL(k_megakernel_ts<false>, dim3(r->ts_blocks), dim3(kTsBlock), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode,
-                                   r->rr_start, d_f32, d_u8, r->d_ray_counter, r->ts_slots, (unsigned long long*)nullptr);
-            }
-#endif
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
             HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(RT_MEGA_BLOCK), pad, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(RT_MEGA_BLOCK), pad, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
@@ -850,12 +804,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                      rays, h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4],
                      h[4] ? (double)h[5] / h[4] : 0.0, (h[0] + h[2]) ? (double)h[6] / (h[0] + h[2]) : 0.0,
                      rays ? (double)h[1] / rays : 0.0, rays ? (double)h[7] / rays : 0.0, rays ? (double)h[3] / rays : 0.0);
-        if (r->mega_ts && h[8])
-            std::fprintf(stderr, "[rt stats ts] T: %llu rounds of %d steps (%.1f lanes holding a slot), %llu idle polls, %llu refills (%.1f slots each), "
-                         "%.0f cycles per round incl. idle, %.0f of them in the steps | S: %llu rounds (%.1f lanes), %.0f cycles per round\n",
-                         h[8], RT_MEGA_UNROLL, (double)h[12] / h[8], h[9], h[10], h[10] ? (double)h[11] / h[10] : 0.0, (double)h[13] / h[8], (double)h[6] / h[8],
-                         h[4], h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[14] / h[4] : 0.0);
-        if (!r->mega_ts && h[10])
+        if (h[10])
             std::fprintf(stderr, "[rt stats] waves %llu | cycles per wave: mean %.0f, max %llu | traversal %.1f%%, shading %.1f%% of wave time | "
                          "%.0f cycles per traversal step, %.0f per shade round\n",
                          h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
@@ -947,7 +896,6 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
     s->device = device;
     if (device >= 0) {
         rc = device_ok(device);
-#if RT_NODE_OFFSETS && !RT_WIDE_NODES
         if (rc == RT_OK) {
             if (s->hs.nodes.size() > (size_t)(0x7FFFFFFF / 64)) { // (a tree of 33 M nodes: ~130 M triangles)
                 rt_scene_destroy(s);
@@ -959,28 +907,6 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
                     if (n.child[k] >= 0) n.child[k] *= 64;
             rc = upload(dn, &s->dev.nodes, s->device_bytes);
         }
-#else
-        if (rc == RT_OK) rc = upload(s->hs.nodes, &s->dev.nodes, s->device_bytes);
-#endif
-#if RT_WIDE_NODES
-        if (rc == RT_OK) {
-            std::vector<WideNode> wide(s->hs.nodes.size());
-            for (size_t i = 0; i < wide.size(); ++i) {
-                const BvhNode& n = s->hs.nodes[i];
-                WideNode& w = wide[i];
-                std::memset(&w, 0, sizeof(w));
-                for (int k = 0; k < 4; ++k) {
-                    for (int a = 0; a < 3; ++a) {
-                        const float lo = n.origin[a] + (float)((n.q[2 * a] >> (8 * k)) & 0xffu) * n.scale(a);
-                        const float hi = n.origin[a] + (float)((n.q[2 * a + 1] >> (8 * k)) & 0xffu) * n.scale(a);
-                        w.plane[2 * a][k] = std::nextafter(lo, -INFINITY), w.plane[2 * a + 1][k] = std::nextafter(hi, INFINITY);
-                    }
-                    w.child[k] = n.child[k] >= 0 ? n.child[k] * 128 : n.child[k];
-                }
-            }
-            rc = upload(wide, &s->dev.wnodes, s->device_bytes);
-        }
-#endif
         if (rc == RT_OK) { // the device's triangle records: the host records' ten live dwords at a kTriBytes stride
             std::vector<uint8_t> packed(s->hs.tris.size() * (size_t)kTriBytes + 16, 0); // + 16: a 16-byte load at the last record's offset 32 stays inside
             for (size_t i = 0; i < s->hs.tris.size(); ++i) std::memcpy(packed.data() + i * kTriBytes, &s->hs.tris[i], std::min<size_t>(kTriBytes, sizeof(TriRec)));
@@ -1011,7 +937,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
-        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.wnodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
+        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
         (void)hipFree((void*)s->dev.inst), (void)hipFree((void*)s->dev.mats), (void)hipFree((void*)s->dev.tex);
     }
     delete s;
@@ -1090,10 +1016,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
-#if RT_WITH_TS
-    if (const char* e = std::getenv("RT_MEGA_TS")) r->mega_ts = e[0] == '1' && kind == RT_RENDERER_MEGAKERNEL;
-#endif
-    if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
+    if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
         return code;
@@ -1117,7 +1040,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (const char* e = std::getenv("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
         if ((std::getenv("RT_WF_REQUEUE") || std::getenv("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
         if (const char* e = std::getenv("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
-        if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)RT_MEGA_WAVES, std::atoi(e)));
+        if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
         if (const char* e = std::getenv("RT_WF_SHOOT_STATIC_PCT")) r->wf_shoot_static_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));

@@ -25,51 +25,17 @@ struct alignas(64) BvhNode {
     uint32_t q[6]; // qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z
     float scale_y, scale_z;
     int32_t child[4];
-    // (RT_ORDERED builds keep a one-hot "ordering axis" flag in the sign bits of the three grid steps: the step itself is |scale|)
     float scale(int a) const { const float s = a == 0 ? scale_x : (a == 1 ? scale_y : scale_z); return s < 0.0f ? -s : s; }
     void set_scale(int a, float s) { (a == 0 ? scale_x : (a == 1 ? scale_y : scale_z)) = s; }
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 constexpr int32_t kChildEmpty = (int32_t)0x80000000;
 
-// RT_WIDE_NODES=1: the traversal kernels read the SAME tree from 128-byte nodes whose child boxes are fp32 planes, grouped so that the
-// four children's planes of one (axis, side) are one 16-byte word: a ray picks its near / far planes by ADDRESS (offset 0 / 16 within
-// the axis' 32 bytes, fixed per ray) instead of selecting packed bytes, and needs no byte -> float conversions: per inner step 24
-// v_cvt_f32_ubyte, 6 v_cndmask and 3 v_cmp (all half-rate instructions) and the 6 setup multiplies go, 7 sixteen-byte loads replace 4.
-//   bytes 0-15 lo_x[4], 16-31 hi_x[4], 32-47 lo_y[4], 48-63 hi_y[4], 64-79 lo_z[4], 80-95 hi_z[4], 96-111 child[4], 112-127 unused
-// child >= 0: BYTE offset of the child node (index * 128); child < 0: the leaf code of BvhNode. Derived on the host from the quantised
-// nodes (planes decoded, lo rounded down / hi up), so both formats cull identically; the quantised array stays the canonical tree
-// (rt_scene_check_bvh, rt_scene_info).
-#ifndef RT_WIDE_NODES
-#define RT_WIDE_NODES 0
-#endif
-struct alignas(128) WideNode {
-    float plane[6][4];
-    int32_t child[4];
-    uint32_t pad[4];
-};
-static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
-
-// RT_ORDERED=1 (experiment): the builder stores every node's children in ascending order of their centroids along
-// the axis on which they are spread widest and marks that axis by the sign bit of its grid step; the inner step then visits the
-// children front to back by the SIGN of the ray's direction on that axis (forward or reverse slot order) and needs neither entry
-// distances as sort keys nor a sorting network. Which hit child is taken first can differ from the exact nearest, so node visits
-// may grow: measured in DESIGN.md.
-#ifndef RT_ORDERED
-#define RT_ORDERED 0
-#endif
-// RT_NODE_OFFSETS=1 (default): in the DEVICE copy of the node array a child word >= 0 is the child node's BYTE offset (index * 64), so that
-// the inner step addresses the node with no arithmetic of its own — a 32-bit offset on the scalar base for global memory (the index form
-// cost a 64-bit shift and a 64-bit add per step), one right shift for the LDS copy of the tree's top. The host array keeps indices.
-#ifndef RT_NODE_OFFSETS
-#define RT_NODE_OFFSETS 1
-#endif
-#ifndef RT_MAX_LEAF_TRIS
-#define RT_MAX_LEAF_TRIS 2 // round 3: 4 -> 2, +1.1 % on the atrium (whose SAH tree had a few 3- and 4-triangle leaves: a whole-leaf step runs as many tests as the
-                           // wave's LARGEST leaf), -0.5 % on the voxel terrain (one block face = 2 triangles per leaf either way); 3: +-0. The whole-leaf loop is
-                           // bounded by this constant (rt_device.h, trav_leaf)
-#endif
-constexpr int kMaxLeafTris = RT_MAX_LEAF_TRIS; // 1..4 (the leaf code keeps count - 1 in two bits)
+// In the DEVICE copy of the node array a child word >= 0 is the child node's BYTE offset (index * 64), so that the inner step
+// addresses the node with no arithmetic of its own — a 32-bit offset on the scalar base for global memory (the index form cost a
+// 64-bit shift and a 64-bit add per step), one right shift for the LDS copy of the tree's top. The host array keeps indices.
+constexpr int kMaxLeafTris = 2;    // 1..4 (the leaf code keeps count - 1 in two bits). 4 -> 2: +1.1 % on the atrium — a whole-leaf step runs as many tests as the wave's LARGEST leaf
+constexpr int kTopNodes = 341;    // nodes at the head of the node array laid out breadth first (scene_build.cpp) and staged in LDS by the traversal kernels (rt_device.h)
 constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64
 constexpr uint32_t kNoTri = 0xFFFFFFFFu;
 constexpr float kTNear = 0.0001f;   // RayData::to_embree tnear (src/camera.hpp:50)
@@ -86,10 +52,7 @@ struct alignas(16) TriRec {
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 // What the device reads per triangle: the record's ten live dwords, packed (the two padding words were 17 % of the
 // triangle traffic): bytes 0-15 (v0.xyz, e1.x), 16-31 (e1.yz, e2.xy), 32-39 (e2.z, global index) at a 40-byte stride (8-byte aligned).
-#ifndef RT_TRI_BYTES
-#define RT_TRI_BYTES 40
-#endif
-constexpr uint32_t kTriBytes = RT_TRI_BYTES; // 40 (packed) or 48 (the host record as it is)
+constexpr uint32_t kTriBytes = 40;
 
 // ---- per-triangle shading attributes, GLOBAL order: 64 bytes ------------------------------------
 // What trace_ray gathers through index_buffer/normal_buffer/uv_buffer (src/trace_ray.hpp:34-45),
@@ -129,7 +92,7 @@ static_assert(sizeof(MatRec) == 48, "MatRec must be 48 bytes");
 // device pointers of one scene replica
 struct SceneDev {
     const BvhNode* nodes;
-    const WideNode* wnodes; // RT_WIDE_NODES builds only (else null)
+    const void* reserved;
     const uint8_t* tris; // leaf order, kTriBytes per triangle
     const ShadeRec* shade;
     const InstRec* inst;

@@ -617,10 +617,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     hs.sky[0] = d->sky[0], hs.sky[1] = d->sky[1], hs.sky[2] = d->sky[2];
     hs.n_layers = d->n_layers;
     if (d->n_layers) hs.tex.assign(d->textures, d->textures + (size_t)d->n_layers * 512u * 512u * 4u);
-#ifndef RT_PACKED_MAT
-#define RT_PACKED_MAT 1 // (0: A/B builds)
-#endif
-    hs.packed_mat = RT_PACKED_MAT && d->n_instances <= (1u << kPackedInstBits) && d->n_materials <= (1u << (32u - kPackedInstBits));
+    hs.packed_mat = d->n_instances <= (1u << kPackedInstBits) && d->n_materials <= (1u << (32u - kPackedInstBits));
     hs.inst.resize(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         std::memcpy(hs.inst[i].normal_mat, d->instances[i].normal_mat, sizeof(float) * 9);
@@ -855,10 +852,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         if (dist < best[n][k - 1]) gather(g.left, dl, kids, nk), gather(g.right, k - dl, kids, nk);
         else gather(n, k - 1, kids, nk);
     };
-#ifndef RT_TOP_NODES
-#define RT_TOP_NODES 341 // must equal rt_device.h's: the nodes the traversal kernels stage in LDS
-#endif
-    constexpr size_t kBfsNodes = RT_TOP_NODES;
+    constexpr size_t kBfsNodes = kTopNodes; // the nodes the traversal kernels stage in LDS
     q.push_back({0, 0, 0});
     while (!q.empty()) {
         Item it;
@@ -889,23 +883,6 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
                 kids[nk++] = c.right;
             }
         }
-#if RT_ORDERED // children in ascending order of their centroids along the axis on which the centroids are spread widest (rt_types.h)
-        int order_axis = 0;
-        {
-            float spread = -1.0f;
-            for (int a = 0; a < 3; ++a) {
-                float lo = std::numeric_limits<float>::infinity(), hi = -lo;
-                for (int k = 0; k < nk; ++k) {
-                    const float c = b.nodes[kids[k]].lo[a] + b.nodes[kids[k]].hi[a];
-                    lo = std::min(lo, c), hi = std::max(hi, c);
-                }
-                if (hi - lo > spread) spread = hi - lo, order_axis = a;
-            }
-            std::stable_sort(kids, kids + nk, [&](int32_t x, int32_t y) {
-                return b.nodes[x].lo[order_axis] + b.nodes[x].hi[order_axis] < b.nodes[y].lo[order_axis] + b.nodes[y].hi[order_axis];
-            });
-        }
-#endif
         BvhNode out = empty_node();
         Item pending[4];
         int n_pending = 0;
@@ -913,9 +890,6 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         for (int k = 0; k < nk; ++k)
             for (int a = 0; a < 3; ++a) klo[k][a] = b.nodes[kids[k]].lo[a] - hs.pad, khi[k][a] = b.nodes[kids[k]].hi[a] + hs.pad;
         if (!quantise_node(out, nk, klo, khi)) { err = "internal: quantisation failed"; return RT_ERR_INVALID; }
-#if RT_ORDERED
-        out.set_scale(order_axis, -out.scale(order_axis));
-#endif
         for (int k = 0; k < nk; ++k) {
             const GNode& c = b.nodes[kids[k]];
             if (c.left < 0) {
