@@ -43,7 +43,6 @@ import glob
 import json
 import os
 import shutil
-import socket
 import subprocess
 import sys
 import tempfile
@@ -107,11 +106,10 @@ def parse_args(argv=None):
 def launch_ranks(args) -> int:
     """Starts N ranks of this script with torch.distributed.run as a CHILD process (never an exec: nothing in this process has touched
     the GPU, and nothing will). Returns the child's exit code; its stdout (the JSON line of rank 0) is passed through."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    # --standalone: the launcher picks and OWNS a free rendezvous port (binding port 0 here and handing the number on would leave a
+    # window in which another process can take it: concurrent runs on one box collided that way)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -163,7 +161,9 @@ def main() -> int:
 
     W, H, strip = args.width, args.height, 8
     F0 = max(1, args.frames_in_flight)
-    fgs = [FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist) for _ in range(max(F0, 2))]  # one strip buffer per frame in flight
+    # strip buffers: one per frame in flight + ONE more, so that the exchange of frame i (async gather, rtamd/dist.py) overlaps with
+    # the rendering of frame i + 1 into another buffer
+    fgs = [FrameGatherer(rank, world, W, H, strip, dev, collective=use_dist) for _ in range(max(F0, 2) + 1)]
     fg = fgs[0]
 
     def barrier():
@@ -179,16 +179,34 @@ def main() -> int:
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         comm_ranks = int(ones.item())
 
+    setup = {"scene_s": 0.0, "bvh_build_upload_s": 0.0, "renderers_s": 0.0}  # this rank's time before the timed regions
+    scene_digests = None
     if rehearsal:
         tile = torch.from_numpy(np.load(Path(args.rehearsal_tiles) / f"tile_{rank}.npy"))
         assert tile.shape[0] == fg.rows and tile.shape[1] == W, (tile.shape, fg.rows, W)
-        scene = sd = cam = None
+        scene = cam = None
+        # the shared-scene path of the real run, rehearsed: generated by rank 0, read by the others, and every rank says what it holds
+        t_setup = time.perf_counter()
+        sd = shared_scene(args, rank, world, use_dist)
+        setup["scene_s"] = round(time.perf_counter() - t_setup, 3)
+        import hashlib
+        mine = hashlib.sha1(b"".join(np.ascontiguousarray(a).tobytes() for a in (sd.positions, sd.normals, sd.uvs, sd.indices, sd.tri_instance, sd.textures))).hexdigest()
+        scene_digests = [mine]
+        if use_dist:
+            scene_digests = [None] * world
+            dist.all_gather_object(scene_digests, mine)
     else:
         from rtamd import abi, scenes
         from rtamd.renderer import Camera, MegakernelRenderer, Scene, WavefrontRenderer
-        sd = scenes.atrium_scene(args.detail)
+        t_setup = time.perf_counter()
+        sd = shared_scene(args, rank, world, use_dist)
+        setup["scene_s"] = round(time.perf_counter() - t_setup, 3)
+        t_setup = time.perf_counter()
         scene = Scene(sd, device=local_rank, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+        setup["bvh_build_upload_s"] = round(time.perf_counter() - t_setup, 3)
         cam = Camera.for_scene(sd, (W, H))
+
+    last_buffer = [0]  # the strip buffer of the last frame rendered (rank 0's gathered frame lives in that FrameGatherer)
 
     def make_renderer(name):
         cls = MegakernelRenderer if name == "megakernel" else WavefrontRenderer
@@ -206,15 +224,19 @@ def main() -> int:
     def measure(name, F=F0):
         """W warm-up frames, then exactly K timed frames of one renderer: render this rank's strips, gather (RCCL), de-interleave on
         rank 0; barrier + synchronize on both sides; MAX over ranks of the time, SUM of the rays."""
+        t_r = time.perf_counter()
         rs = [] if rehearsal else [make_renderer(name) for _ in range(F)]
+        setup["renderers_s"] = round(setup["renderers_s"] + time.perf_counter() - t_r, 3)
+        NB = len(fgs)
         if rs:
             assert fg.rows == rs[0].local_rows
         tot = {"rays": 0, "hot_ms": 0.0, "hot_launches": 0, "dev_ms": 0.0, "gather_s": 0.0, "kernel_ms": {}, "kernels": {}, "lanes": 0}
 
-        def collect(k):
-            """wait for frame buffer k's frame, gather it (gather of the per-GPU strip buffers + de-interleave on rank 0)"""
+        def collect(k, b):
+            """wait for renderer k's frame in strip buffer b, START its exchange (gather of the per-GPU strip buffers; the de-interleave on
+            rank 0 follows in gather_end, when buffer b is needed again or the run ends)"""
             if rehearsal:
-                fgs[k].local[: tile.shape[0]].copy_(tile)
+                fgs[b].local[: tile.shape[0]].copy_(tile)
                 rays = 0
             else:
                 fr = rs[k].end_frame()
@@ -228,7 +250,7 @@ def main() -> int:
                 for kn, v in fr.kernels.items():
                     tot["kernels"][kn] = tot["kernels"].get(kn, 0) + v
             t = time.perf_counter()
-            fgs[k].gather()
+            fgs[b].gather_begin()
             tot["gather_s"] += time.perf_counter() - t
             tot["rays"] += rays
 
@@ -237,14 +259,23 @@ def main() -> int:
             strip buffer) while frame i finishes and is gathered: the next frame's waves fill the end-of-frame drain"""
             queue = []
             for i in range(n):
-                k = i % F
+                k, b = i % F, i % NB
                 if len(queue) == F:
-                    collect(queue.pop(0))
-                if not rehearsal:
-                    rs[k].begin_frame(cam, d_f32=fgs[k].local.data_ptr())
-                queue.append(k)
+                    collect(*queue.pop(0))
+                t = time.perf_counter()
+                fgs[b].gather_end()  # the exchange that last used this buffer (NB - 1 frames ago): long complete, this is where it is retired
+                tot["gather_s"] += time.perf_counter() - t
+                if not rehearsal:  # the frame as the reference's K1 writes it: fp32 tile AND the RGBA-unorm8 image (src/render_megakernel.cpp:154-158)
+                    rs[k].begin_frame(cam, d_f32=fgs[b].local.data_ptr(), d_u8=fgs[b].local_u8.data_ptr())
+                queue.append((k, b))
             while queue:
-                collect(queue.pop(0))
+                collect(*queue.pop(0))
+            t = time.perf_counter()
+            for g in fgs:
+                g.gather_end()
+            tot["gather_s"] += time.perf_counter() - t
+            if n:
+                last_buffer[0] = (n - 1) % NB
 
         run(args.warmup)
         barrier()
@@ -257,7 +288,7 @@ def main() -> int:
         kernel_frames = args.steps
         if rs and name.startswith("wavefront_per_bounce"):  # the per-kernel durations: one profiled frame outside the timed region
             rs[0].set_profiling(True)
-            fr = rs[0].render_frame_device(cam, d_f32=fgs[0].local.data_ptr())
+            fr = rs[0].render_frame_device(cam, d_f32=fgs[0].local.data_ptr(), d_u8=fgs[0].local_u8.data_ptr())
             tot["kernel_ms"], tot["hot_ms"], tot["hot_launches"], kernel_frames = dict(fr.kernel_ms), fr.hot_kernel_ms, fr.hot_kernel_launches, 1
             tot["profiled_rays"] = fr.rays
         for r in rs:
@@ -295,6 +326,10 @@ def main() -> int:
             lead = box[0]
         pipelined = measure(lead, 2) if F0 == 1 and not args.no_pipelined else None
 
+    setup_all = [setup]
+    if use_dist:
+        setup_all = [None] * world
+        dist.all_gather_object(setup_all, setup)
     if rank == 0:
         best = max(results, key=lambda d: d["value"])  # headline: the fastest of the path's renderers
         workload = (f"atrium (Sponza-like, {sd.n_triangles} tris) {W}x{H} {args.spp}spp depth {args.depth}" if not rehearsal
@@ -309,6 +344,7 @@ def main() -> int:
             "device_ms_per_step": best["device_ms_per_step"],
             "per_rank_ms": best["per_rank_ms"], "gather_ms": best["gather_ms"],
             "rccl_ranks": comm_ranks, "backend": args.backend if use_dist else None,
+            "setup_s_per_rank": setup_all, "scene_digests": scene_digests,  # before the timed regions: scene generated (rank 0) or read from rank 0's file, BVH built + uploaded, renderers created
             "renderers": {d["renderer"]: d for d in results},
         }
         if pipelined:
@@ -321,13 +357,36 @@ def main() -> int:
         if world == 1 and not rehearsal and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
         if args.dump_frame:
-            np.save(args.dump_frame, fg.frame.cpu().numpy())
+            np.save(args.dump_frame, fgs[last_buffer[0]].frame.cpu().numpy())
         print(json.dumps(out), flush=True)
     if scene is not None:
         scene.close()
     if use_dist:
         dist.destroy_process_group()
     return 0
+
+
+def shared_scene(args, rank, world, use_dist):
+    """The bench scene, GENERATED once per run: rank 0 writes it to one file, the other ranks read it (1.1 s of Python per rank
+    otherwise, N times concurrently on one host). Every rank then builds its own BVH replica from it (rt_scene_create: 0.5 s)."""
+    import torch.distributed as dist
+    from rtamd import scenes
+    if not (use_dist and world > 1):
+        return scenes.atrium_scene(args.detail)
+    box = [None]
+    if rank == 0:
+        fd, shared = tempfile.mkstemp(prefix="rt_bench_scene_", suffix=".npz")
+        os.close(fd)
+        sd = scenes.atrium_scene(args.detail)
+        scenes.save_scene(sd, shared)
+        box = [shared]
+    dist.broadcast_object_list(box, src=0)  # (also the barrier: the file is complete when its name arrives)
+    if rank != 0:
+        sd = scenes.load_scene(box[0])
+    dist.barrier()
+    if rank == 0:
+        os.unlink(box[0])
+    return sd
 
 
 def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 6
+#define RT_ABI_VERSION 7
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -278,6 +278,11 @@ typedef struct rt_stats {
     /* with profiling on (rt_renderer_set_profiling): summed hipEvent duration of the launches of the traversal / shading kernel
      * families (RT_K_MEGAKERNEL, RT_K_WF_EXTEND, RT_K_WF_SHADE, RT_K_WF_SHOOT, RT_K_WF_FINISH), each on the stream it was launched on; else 0 */
     double kernel_ms[RT_K_COUNT];
+    /* (ABI 7) hardware queues the library assumed HIP serves the process's streams from: GPU_MAX_HW_QUEUES as the HOST had set it when the
+     * renderer was created, 4 (HIP's default) when unset. The library never changes the environment; an automatic stream-lane count is resolved
+     * down to lanes + 2 <= hw_queues (the frame's stream and one stream of the host framework beside the lanes'), see stream_lanes above. */
+    uint32_t hw_queues;
+    uint32_t reserved0;
 } rt_stats;
 
 /* == IRenderer::render_frame(camera, scene) (src/render_megakernel.cpp:75-187,

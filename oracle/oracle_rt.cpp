@@ -23,6 +23,9 @@
 //   R4  std::hash<size_t> is the identity (libstdc++), so seeds are the pixel index itself.
 //   R5  closest hit = over ALL triangles, Moller-Trumbore as written in mt_hit(); accept
 //       t > 1e-4; minimum t wins, equal t -> lowest global triangle index. A BVH may only cull.
+//       The triangle test is NOT the reference's arithmetic (that lives inside Embree: src/trace_ray.hpp:22) but this repository's
+//       convention, so it is the one place where the operations are FUSED (round 4): its cross and dot products are
+//       cross_f / dot_f below — every a*b + c of them a single fmaf (one rounding). R1 holds everywhere else.
 //   R6  instance transform: world = ((m0*x + m4*y) + m8*z) + m12 per row (column-major 4x4).
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fno-fast-math).
@@ -193,24 +196,29 @@ constexpr uint32_t NO_TRI = 0xFFFFFFFFu;
 constexpr float T_NEAR = 0.0001f; // RayData::to_embree tnear, src/camera.hpp:50
 
 // R5: Moller-Trumbore; barycentrics follow Embree's convention P = (1-u-v) v0 + u v1 + v v2
-// (usage at src/trace_ray.hpp:48-54).
+// (usage at src/trace_ray.hpp:48-54). The fused forms of R5 (each fmaf rounds once):
+inline float dot_f(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+inline V3 cross_f(V3 a, V3 b) {
+    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
 inline void mt_hit(const Tri& tr, uint32_t idx, V3 o, V3 d, Hit& best) {
     // Edge tests are made on the un-divided numerators (sign-corrected by det), so the one
     // correctly-rounded division is spent only on triangles that pass them.
-    V3 p = cross(d, tr.e2);
-    float det = dot(tr.e1, p);
+    V3 p = cross_f(d, tr.e2);
+    float det = dot_f(tr.e1, p);
     if (!(det != 0.0f)) return; // parallel (or NaN)
     V3 tv = o - tr.v0;
-    V3 q = cross(tv, tr.e1);
+    V3 q = cross_f(tv, tr.e1);
     float sgn = det < 0.0f ? -1.0f : 1.0f;
-    float un = dot(tv, p) * sgn;
-    float vn = dot(d, q) * sgn;
+    float un0 = dot_f(tv, p), vn0 = dot_f(d, q);
+    float un = un0 * sgn;
+    float vn = vn0 * sgn;
     if (!(un >= 0.0f && vn >= 0.0f && un + vn <= fabsf(det))) return;
     float inv = 1.0f / det;
-    float t = dot(tr.e2, q) * inv;
+    float t = dot_f(tr.e2, q) * inv;
     if (!(t > T_NEAR)) return;
-    float u = dot(tv, p) * inv;
-    float v = dot(d, q) * inv;
+    float u = un0 * inv;
+    float v = vn0 * inv;
     if (t < best.t || (t == best.t && idx < best.tri)) {
         best.t = t;
         best.u = u;

@@ -113,6 +113,18 @@ constexpr uint32_t kMegaBlock = 512;   // threads per workgroup: 8 independent w
 constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compiled for (80 VGPRs): 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
 constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
 constexpr uint32_t kMegaShadePct = 75; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
+#ifndef RT_CHAIN_UNROLL
+#define RT_CHAIN_UNROLL 3
+#endif
+#ifndef RT_CHAIN_WAVES
+#define RT_CHAIN_WAVES 4
+#endif
+#ifndef RT_CHAIN_BOTH
+#define RT_CHAIN_BOTH 0
+#endif
+constexpr uint32_t kChainWaves = RT_CHAIN_WAVES; // the chain regime's instantiation: a tile of one pixel generation fills 4 waves per SIMD at most (128 VGPRs)
+constexpr bool kChainBoth = RT_CHAIN_BOTH != 0;
+constexpr int kChainUnroll = RT_CHAIN_UNROLL; // ... in the chain regime's instantiation (an iteration there is an inner AND a leaf step)
 constexpr uint32_t kMegaRefill = 1;    // idle lanes that trigger a pixel fetch — as the STARTING value of RefillPolicy:
 // A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
 // part, and a lane that waits for company is idle: with lanes falling idle at a rate L per unit of wave time, refilling at T idle lanes
@@ -144,8 +156,9 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
         }
     }
 };
-template <bool STATS>
-__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+// CHAIN: the instantiation for tiles of (about) one pixel generation: both step kinds per iteration (trav_step_both)
+template <bool STATS, bool CHAIN = false>
+__global__ void __launch_bounds__(kMegaBlock, CHAIN ? kChainWaves : kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
@@ -175,20 +188,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
     RefillPolicy refill;    // idle lanes that trigger a pixel fetch: set per wave from the pixels it finishes
-    bool exhausted = false; // wave-uniform: every region's cursor has passed its last slot
-    // RT_MEGA_XCD_REGIONS=1 (round 1's default, now OFF): the frame's pixel slots cut into 8 contiguous regions, one per XCD — a wave
-    // first drains the region of the XCD it runs on (HW_REG_XCC_ID), then helps with the others, so that waves which share an L2 work
-    // on one part of the picture. That paid (+4 %) while the kernel was sensitive to L2 misses; now that it is bound by instruction
-    // issue, what matters is that all waves advance over ONE front and the frame's last pixels are not all in the region that happened
-    // to be slowest: one frame-wide cursor, atrium 1080p 16 spp 38.72 -> 37.83 ms, Cornell box 1024x1024 64 spp 29.8 -> 25.2 ms
-    // (its regions differ a lot in cost: ceiling and light, walls, floor).
-    const uint32_t region_slots = (n_slots + 63u) & ~63u; // one region: the frame
-    uint32_t region = 0;
-    uint32_t regions_done = 7;
-    const uint32_t region_left = region_slots;                                                  // slots of one region
-    const uint32_t waves_per_region = (gridDim.x * (kMegaBlock / 64u) + 7u) / 8u;           // the waves that start on it
-    uint32_t last_base = 0; // cursor of the current region as this wave last saw it
-    (void)region_left, (void)waves_per_region, (void)last_base; // only read with RT_MEGA_GSS
+    bool exhausted = false; // wave-uniform: the frame's pixel cursor has passed the last slot
+    // (ONE frame-wide cursor. Round 1 cut the frame into a region per XCD, for L2 locality: +4 % then, -2 % ... -16 % once the kernel was bound
+    // by instruction issue — all waves should advance over one front, or the frame's last pixels all lie in the slowest region. EXPERIMENTS.md)
     auto start_pixel = [&](uint32_t p) { // pixel slot p (8x8-tile order) becomes this lane's pixel; slots outside the image are skipped
         const uint32_t t = p >> 6; // (slots in row order instead of 8x8 blocks: +-0 on both scenes)
         x = (int)((t % tiles_x) * 8u + (p & 7u));
@@ -224,29 +226,16 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         if (!exhausted) {
             const unsigned long long idle_m = __ballot(!live);
             const uint32_t cnt = (uint32_t)__popcll(idle_m);
-            // RT_MEGA_GSS=1 (experiment, OFF): guided self-scheduling of the pixel queue — a wave may hold at most remaining pixels /
-            // waves live lanes, so that the last pixels of the queue (and all pixels of a small tile) are spread thinly over ALL
-            // waves instead of filling a few of them. The idea was that a pixel's chain runs faster in a wave with few live lanes.
-            // It does not: a lane whose traversal is complete still waits for kMegaShadePct of its wave, so the chain is paced
-            // by the slowest lanes whatever their number. Measured (64 spp, 1080p atrium): full frame 153 -> 210 ms (the last fifth
-            // of every region runs in under-filled waves), 1/8 tile 34.1 -> 32.1 ms, 1/16 tile 28.6 -> 29.0 ms. Scheduling only:
-            // every pixel is computed exactly as before.
-            uint32_t take = cnt;
-            if (cnt >= refill.threshold() && take) {
-                // (one cursor per region; one region = the frame unless RT_MEGA_XCD_REGIONS. Speed only: any placement gives the same image.)
+            if (cnt >= refill.threshold()) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(pixel_cursor + region, take);
+                if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                last_base = base + take;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                const uint32_t rel = base + rank;
-                const uint32_t p = region * region_slots + rel;
-                if (!live && rank < take && rel < region_slots && p < n_slots) start_pixel(p);
-                if (base + take >= region_slots) { // this region is used up: move on to the next one
-                    region = (region + 1u) & 7u;
-                    last_base = 0;
-                    exhausted = ++regions_done >= 8u;
-                    if (STATS && exhausted) wall_exhausted = wall_clock64();
+                const uint32_t p = base + rank;
+                if (!live && p < n_slots) start_pixel(p);
+                if (base + cnt >= n_slots) {
+                    exhausted = true;
+                    if (STATS) wall_exhausted = wall_clock64();
                 }
             }
         }
@@ -255,25 +244,21 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             if (exhausted) break;
             continue;
         }
-        // TRAVERSE until at least half of the live lanes are waiting for shading
+        // TRAVERSE until kMegaShadePct of the live lanes are waiting for shading
         if (STATS) t_mark = (long long)__builtin_readcyclecounter();
-        bool miss_round = false; // RT_MEGA_MISS_ROUND: this round only ends the paths that missed
-        (void)miss_round;
         const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
-        uint32_t lingered = 0; // RT_MEGA_LINGER
-        (void)lingered;
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * (exhausted ? kMegaShadePct : kMegaShadePct)) {
-                break;
-            }
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * kMegaShadePct) break;
             if (STATS) ws.live_lane_steps += n_live;
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            if (CHAIN && kChainBoth) trav_step_both<STATS>(S, T, stack, top, sg, &ws);
+            else (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < kMegaUnroll; ++k) { // the exit tests are checked every kMegaUnroll steps
+            for (int k = 1; k < (CHAIN ? kChainUnroll : kMegaUnroll); ++k) { // the exit tests are checked every kMegaUnroll steps
                 if (STATS) ws.live_lane_steps += n_live;
-                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+                if (CHAIN && kChainBoth) trav_step_both<STATS>(S, T, stack, top, sg, &ws);
+                else (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
@@ -284,7 +269,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         // SHADE the lanes whose traversal is complete
         __builtin_amdgcn_s_setprio(0);
         bool pixel_finished = false;
-        if (!miss_round) wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
+        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
         if (live && T.cur == kTravDone) {
             f3 res;
             const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
@@ -328,6 +313,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         atomicMin(stats_out + 13, wall_begin);
         if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
         atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
+        atomicAdd(stats_out + 16, ws.t_in_fetch), atomicAdd(stats_out + 17, ws.t_in_test), atomicAdd(stats_out + 18, ws.t_in_stack);
+        atomicAdd(stats_out + 19, ws.t_lf_fetch), atomicAdd(stats_out + 20, ws.t_lf_rest);
     }
 }
 

@@ -130,6 +130,7 @@ struct rt_renderer {
     uint32_t max_depth = 0, spp = 0, seed_mode = 0;
     TileDev tile{0, 1, 8, 0};
     uint32_t n_local = 0; // pixels in this tile
+    bool unusable = false; // the last (re-)allocation of the tile's buffers failed: no frame until one succeeds
     int n_cus = 256;      // compute units of the device (persistent-kernel grid sizing)
     hipStream_t stream = nullptr;
     // outputs (device) used when the caller passes host pointers
@@ -204,6 +205,11 @@ struct rt_renderer {
     hipStream_t graph_stream = nullptr;
     LaunchCount graph_launches{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // rt_frame_gather_begin reads the renderer's tile buffers (d_f32 / d_u8) asynchronously, ordered on the renderer's OWN stream. A next frame
+    // begun on a caller's stream is not ordered behind that: ev_tile_read (recorded on the own stream behind the send / the copies) is what
+    // frame_begin makes such a stream wait for before anything writes the tile again.
+    hipEvent_t ev_tile_read = nullptr;
+    bool tile_read_recorded = false;
     // the frame between rt_render_frame_begin and rt_render_frame_end
     bool frame_pending = false;
     hipStream_t pending_stream = nullptr;
@@ -214,7 +220,9 @@ struct rt_renderer {
     std::vector<hipEvent_t> ev_pool;
     // diagnostics (scripts/occupancy_probe.py): RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
+    uint32_t hw_queues = 4; // GPU_MAX_HW_QUEUES as the host had set it when the renderer was created (4 = HIP's default): bounds the automatic stream lanes
     uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
+    uint32_t mega_chain_pct = 100; // tiles of up to this share of the chip's resident lanes render with k_megakernel<.., CHAIN> (RT_MEGA_CHAIN_PCT; 0 = never)
 };
 
 namespace {
@@ -260,6 +268,8 @@ bool origin_in_contract_range(const HostScene& hs, const float o[3]) {
     float scale = 0.0f;
     for (int a = 0; a < 3; ++a)
         scale = std::max(scale, std::max(hs.bounds_hi[a] - hs.bounds_lo[a], std::max(std::fabs(hs.bounds_lo[a]), std::fabs(hs.bounds_hi[a]))));
+    // a degenerate scene (all geometry in the origin: scale 0) has nothing a box test could cull wrongly: every finite origin is in range
+    if (!(scale > 0.0f)) return std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]);
     const float limit = kContractRange * scale;
     for (int a = 0; a < 3; ++a) {
         const float outside = std::max(std::max(hs.bounds_lo[a] - o[a], o[a] - hs.bounds_hi[a]), 0.0f);
@@ -278,21 +288,26 @@ int32_t rows_of_tile(const TileDev& t, int32_t height) {
 // The wavefront renderer's default schedule: ONE k_wf_generate + ONE k_wf_finish launch per frame, tile and stream lane, every
 // pixel kept in its lane for all its samples (rt_kernels.h): rt_schedule{finish_depth 0, samples_per_launch 0}.
 bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch == 0 && r->sched.finish_depth == 0 && r->max_depth > 0; }
-// stream lanes (interleaved sub-tiles on HIP streams of their own): 1 for the one-launch schedule, 2 where launches have tails to overlap
-// (the split EXTEND + SHADE pipeline of every bounce on 1 / 2 / 3 lanes: 4166 / 4979 / 5213 Mrays/s on the atrium at 1080p, 64 spp when the host
-// thread does nothing else — but three lanes are 4,038 launches per frame, and in a process that also runs torch (bench.py) the host enqueues
-// them slower than the device consumes them: 333 instead of 208 ms. Two lanes, 2,692 launches, stay ahead of the device: the default.)
-// (stream lanes by default: 1 for the one-launch schedule, 3 for a launch (pair) per bounce all the way — 2,118 / 4,038 launches per 64-spp frame;
-//  SHOOT's launches ask for 2 of the 6 wave slots per SIMD each, 4 lanes leave them one and lose a fifth — 2 otherwise.)
-// HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues, 4 by default: with the frame's stream, three lane streams and one stream of
-// the host framework (torch, in bench.py) two lanes shared a queue and ran one after the other — the split pipeline on three lanes took 314 ms
-// per frame inside bench.py against 190 ms from a bare process, and SHOOT on four lanes halved its rate everywhere. The library therefore asks
-// for 8 queues when it is loaded (unless the variable is set): effective if that happens before the process's first HIP call.
-__attribute__((constructor)) void rt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Stream lanes: interleaved sub-tiles of the renderer's tile, each with its own queues on a HIP stream of its own, so that one lane's launch
+// tails overlap with another lane's traversal. 1 for the one-launch schedule; where every bounce is a launch (pair) 3 pay (split EXTEND + SHADE on
+// 1 / 2 / 3 lanes: 4166 / 4979 / 5213 Mrays/s; fused SHOOT on four lanes leaves each launch one wave per SIMD and loses a fifth); 2 otherwise.
+// HIP maps a process's streams onto at most GPU_MAX_HW_QUEUES hardware queues — FOUR unless the host sets the variable before its first HIP call.
+// The frame's stream, three lane streams and the host framework's own stream are five: two lanes then share a queue and their launches run one
+// after the other (measured: the split pipeline on three lanes 314 ms per frame with 4 queues, 191 ms with 8). The library never touches the
+// process environment (round 3 set the variable from a constructor: a side effect of dlopen, and void when HIP was already up). It READS what the
+// host configured when a renderer is created, and resolves an automatic lane count down to what the queues can serve: lanes + 2 <= queues. The
+// host (bench.py, the raytracer CLI) sets GPU_MAX_HW_QUEUES=8 itself before HIP starts; rt_stats reports both numbers.
+uint32_t hw_queues_from_env() {
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? (uint32_t)v : 4u; // HIP's default
+}
 uint32_t wf_stream_lanes(const rt_renderer* r) {
-    if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u);
+    if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u); // explicit: the caller's business
     if (wf_one_launch(r)) return 1u;
-    return r->sched.fused_bounce || r->sched.finish_depth >= r->max_depth ? 3u : 2u;
+    uint32_t want = r->sched.fused_bounce || r->sched.finish_depth >= r->max_depth ? 3u : 2u;
+    while (want > 2u && want + 2u > r->hw_queues) want--;
+    return want;
 }
 // ... and where the tile has no more pixels than the chip has resident lanes (one generation of pixel chains: DESIGN.md §7) the queue
 // hands every wave pixels spread evenly over the tile
@@ -326,26 +341,31 @@ uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
     return (uint32_t)std::max<uint64_t>(1, c);
 }
 
-int alloc_tile_buffers(rt_renderer* r) {
+int alloc_tile_buffers_impl(rt_renderer* r) {
     free_tile_buffers(r);
+    // test hook: RT_INJECT_ALLOC_FAILURE=k makes the k-th device allocation of this call fail as if the device were out of memory
+    // (tests/test_gpu_parity.py: a failed re-allocation must leave a renderer that says so, not one that launches on null queues)
+    int inject = 0, n_alloc = 0;
+    if (const char* e = std::getenv("RT_INJECT_ALLOC_FAILURE")) inject = std::atoi(e);
+    auto dalloc = [&](void** p, size_t bytes) { return inject && ++n_alloc == inject ? hipErrorOutOfMemory : hipMalloc(p, bytes); };
     r->tile.local_rows = rows_of_tile(r->tile, r->height);
     r->n_local = (uint32_t)r->tile.local_rows * (uint32_t)r->width;
     const size_t n = std::max<size_t>(r->n_local, 1);
     const char* ks = std::getenv("RT_KERNEL_STATS");
-    if (ks && ks[0] == '1') HIPCHK(hipMalloc((void**)&r->d_stats, 16 * sizeof(unsigned long long)));
+    if (ks && ks[0] == '1') HIPCHK(dalloc((void**)&r->d_stats, 24 * sizeof(unsigned long long)));
     // sized for the LONGEST tile of the split (rank 0's): ncclGather sends the same count from every rank
     TileDev t0 = r->tile;
     t0.rank = 0;
     const size_t n_pad = std::max<size_t>((size_t)rows_of_tile(t0, r->height) * (size_t)r->width, n);
-    HIPCHK(hipMalloc((void**)&r->d_f32, n_pad * 16));
-    HIPCHK(hipMalloc((void**)&r->d_u8, n_pad * 4));
+    HIPCHK(dalloc((void**)&r->d_f32, n_pad * 16));
+    HIPCHK(dalloc((void**)&r->d_u8, n_pad * 4));
     // the padding rows are gathered too: defined bytes. On the renderer's own stream: a hipMemset on the null stream is not ordered
     // against this non-blocking stream and could land on top of the first frame.
     HIPCHK(hipMemsetAsync(r->d_f32, 0, n_pad * 16, r->stream));
     HIPCHK(hipMemsetAsync(r->d_u8, 0, n_pad * 4, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // ray count + 8 region cursors + error word
+        HIPCHK(dalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // [0] ray count, [1] the frame's pixel cursor (low word)
     } else {
         const uint32_t K = wf_stream_lanes(r);
         const bool per_bounce = r->sched.finish_depth > 0 && r->max_depth > 0; // EXTEND + SHADE launch pairs: the second queue and the hit records
@@ -361,38 +381,52 @@ int alloc_tile_buffers(rt_renderer* r) {
             const size_t mq = m + (per_bounce && r->sched.fused_bounce ? (size_t)kOutBlock * ((size_t)r->n_cus * 4u * kMegaWaves / (kMegaBlock / 64) + 1u) : 0u);
             for (int qi = 0; qi < (per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
                 auto& q = L.q[qi];
-                HIPCHK(hipMalloc((void**)&q.org_id, mq * 16));
-                HIPCHK(hipMalloc((void**)&q.a, mq * 8));
-                HIPCHK(hipMalloc((void**)&q.b, mq * 8));
-                HIPCHK(hipMalloc((void**)&q.c, mq * 2 + 2));
+                HIPCHK(dalloc((void**)&q.org_id, mq * 16));
+                HIPCHK(dalloc((void**)&q.a, mq * 8));
+                HIPCHK(dalloc((void**)&q.b, mq * 8));
+                HIPCHK(dalloc((void**)&q.c, mq * 2 + 2));
             }
-            HIPCHK(hipMalloc((void**)&L.d_rng, m * 4));
-            HIPCHK(hipMalloc((void**)&L.d_accum, m * 16));
-            if (per_bounce && !r->sched.fused_bounce) HIPCHK(hipMalloc((void**)&L.d_hits, m * 16));
+            HIPCHK(dalloc((void**)&L.d_rng, m * 4));
+            HIPCHK(dalloc((void**)&L.d_accum, m * 16));
+            if (per_bounce && !r->sched.fused_bounce) HIPCHK(dalloc((void**)&L.d_hits, m * 16));
             const size_t nc = (size_t)r->spp * ((size_t)r->max_depth + 1);
             // spp * (max_depth + 1) queue lengths, spp * max_depth chunk cursors, spp "extra ray" counters of k_wf_finish
-            HIPCHK(hipMalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
+            HIPCHK(dalloc((void**)&L.d_counts, (nc + (size_t)r->spp * r->max_depth + (size_t)r->spp + 1) * 4));
             L.h_counts.resize(nc);
             L.h_extra.resize((size_t)r->spp + 1); // + the dynamic queue's error word
-            HIPCHK(hipMalloc((void**)&L.d_extra, L.h_extra.size() * 8));
+            HIPCHK(dalloc((void**)&L.d_extra, L.h_extra.size() * 8));
             const uint32_t chunk = wf_chunk(r, L.n_local);
             L.n_tiles = 0;
             if (wf_cost_order(r) && r->width % 8 == 0 && L.tile.local_rows % 8 == 0 && L.n_local) {
                 L.n_tiles = L.n_local / 64u;
-                HIPCHK(hipMalloc((void**)&L.d_cost, L.n_local));
-                HIPCHK(hipMalloc((void**)&L.d_tile_key, (size_t)L.n_tiles * 4));
-                HIPCHK(hipMalloc((void**)&L.d_tile_order, (size_t)L.n_tiles * 4));
+                HIPCHK(dalloc((void**)&L.d_cost, L.n_local));
+                HIPCHK(dalloc((void**)&L.d_tile_key, (size_t)L.n_tiles * 4));
+                HIPCHK(dalloc((void**)&L.d_tile_order, (size_t)L.n_tiles * 4));
             }
             if (chunk > 1 && wf_uses_requeue(r)) { // every pixel is appended once per sample of a launch but its first
                 L.rq_capacity = L.n_local * (chunk - 1u);
-                HIPCHK(hipMalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
-                HIPCHK(hipMalloc((void**)&L.d_rq_ctl, 80 * 4));
+                HIPCHK(dalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
+                HIPCHK(dalloc((void**)&L.d_rq_ctl, 80 * 4));
             }
             HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
     }
     return RT_OK;
+}
+
+// Re-allocation is all or nothing: whatever fails (a device allocation, a stream), nothing half-built survives — the renderer is marked
+// unusable and every frame entry point refuses it until a later rt_renderer_set_tile / rt_renderer_set_schedule succeeds.
+int alloc_tile_buffers(rt_renderer* r) {
+    const int rc = alloc_tile_buffers_impl(r);
+    r->unusable = rc != RT_OK;
+    if (rc != RT_OK) {
+        const std::string msg = g_err;
+        free_tile_buffers(r);
+        r->n_local = 0, r->tile.local_rows = 0;
+        g_err = msg;
+    }
+    return rc;
 }
 
 CameraDev to_dev(const rt_camera& c) {
@@ -419,7 +453,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     LaunchCount launches;
     HIPCHK(hipMemcpyAsync(r->d_cam, r->h_cam, sizeof(CameraDev), hipMemcpyHostToDevice, st));
     const uint32_t D = r->max_depth;
-    if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 16 * sizeof(unsigned long long), st));
+    if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 24 * sizeof(unsigned long long), st));
     // fork: every lane's stream waits for what was enqueued on `st` so far, then runs its own chain
     if (r->lanes.size() > 1) HIPCHK(hipEventRecord(r->ev_fork, st));
     size_t ne_total = 0;
@@ -631,17 +665,22 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         return RT_OK;
     }
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
-        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 8 * sizeof(unsigned long long), st)); // ray count + region cursors
+        HIPCHK(hipMemsetAsync(r->d_ray_counter, 0, 8 * sizeof(unsigned long long), st)); // ray count + pixel cursor
         const uint32_t tiles_x = (uint32_t)(r->width + 7) / 8u, tiles_y = (uint32_t)(r->tile.local_rows + 7) / 8u;
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
         constexpr uint32_t mega_wpb = kMegaBlock / 64;
         // (in the chain regime — fewer tiles than wave slots — 64 pixels on 4,050 waves beat 42 pixels on all 6,144: 29.5 against 33.7 ms)
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
+        // the chain regime's instantiation (rt_device.h: trav_step_both) where the tile is about one generation of pixels: at most
+        // mega_chain_pct per cent of the lanes the chip holds
+        const bool chain = (uint64_t)tiles_x * tiles_y * 64u * 100u <= (uint64_t)r->mega_chain_pct * (uint64_t)r->n_cus * 4u * kMegaWaves * 64u;
         const uint32_t pad = r->mega_lds_pad;
         if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
         }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
@@ -651,11 +690,18 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
-            HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+            HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, 9 * sizeof(unsigned long long), st));
+            if (chain)
+                hipLaunchKernelGGL((k_megakernel<true, true>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+                                   r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+            else
+                hipLaunchKernelGGL((k_megakernel<true, false>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+                                   r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+        } else if (chain) {
+            hipLaunchKernelGGL((k_megakernel<false, true>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         } else {
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL((k_megakernel<false, false>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
@@ -714,13 +760,16 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
 int frame_begin(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u8, hipStream_t st) {
     if (!r || !cam) return fail(RT_ERR_INVALID, "null renderer or camera");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "the renderer's previous frame has not been collected (rt_render_frame_end)");
+    if (r->unusable) return fail(RT_ERR_INVALID, "the renderer has no buffers: its last rt_renderer_set_tile / rt_renderer_set_schedule failed (call either again)");
     if (cam->width != r->width || cam->height != r->height) return fail(RT_ERR_INVALID, "camera size differs from the renderer's image size");
     if (!origin_in_contract_range(r->scene->hs, cam->center))
         return fail(RT_ERR_INVALID, "the camera lies more than 100 scene scales outside the scene's bounds: outside the range of the closest-hit contract (rt_intersect_batch)");
     HIPCHK(hipSetDevice(r->scene->device));
     r->pending_stats = rt_stats{};
+    r->pending_stats.hw_queues = r->hw_queues;
     r->pending_hot = 0;
     r->pending_t0 = std::chrono::high_resolution_clock::now();
+    if (r->tile_read_recorded && st != r->stream) HIPCHK(hipStreamWaitEvent(st, r->ev_tile_read, 0)); // an overlapped gather still reads the tile
     HIPCHK(hipEventRecord(r->ev_begin, st));
     int rc = enqueue_frame(r, cam, d_f32, d_u8, st, &r->pending_stats, &r->pending_hot);
     if (rc != RT_OK) {
@@ -775,7 +824,6 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
             unsigned long long ctr[8] = {0};
             HIPCHK(hipMemcpy(ctr, r->d_ray_counter, sizeof(ctr), hipMemcpyDeviceToHost));
             local.rays = ctr[0];
-            if (ctr[5]) return fail(RT_ERR_HIP, "k_megakernel_ts: a queue entry did not become valid (internal error word set)");
         } else {
             uint64_t rays = 0;
             const uint32_t D = r->max_depth;
@@ -795,7 +843,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
         }
     }
     if (r->d_stats && r->n_local) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         const unsigned long long rays = local.rays;
         HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         std::fprintf(stderr,
@@ -809,6 +857,9 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                          "%.0f cycles per traversal step, %.0f per shade round\n",
                          h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
                          (h[0] + h[2]) ? (double)h[11] / (h[0] + h[2]) : 0.0, h[4] ? (double)h[12] / h[4] : 0.0);
+        if (h[16] && h[0] && h[2])
+            std::fprintf(stderr, "[rt stats] cycles per inner step: fetch %.0f, box tests + sort %.0f, pushes / pop %.0f | per leaf step: fetch %.0f, tests + pop %.0f\n",
+                         (double)h[16] / h[0], (double)h[17] / h[0], (double)h[18] / h[0], (double)h[19] / h[2], (double)h[20] / h[2]);
         if (h[10] && h[15] > h[13] && h[14] != ~0ull)
             std::fprintf(stderr, "[rt stats] frame timeline: %.2f ms in all, pixel queue empty after %.2f ms, drain %.2f ms (%.1f%%)\n",
                          (h[15] - h[13]) * 1e-5, (h[14] - h[13]) * 1e-5, (h[15] - h[14]) * 1e-5, 100.0 * (h[15] - h[14]) / (h[15] - h[13]));
@@ -1013,9 +1064,11 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     r->max_depth = max_depth, r->spp = sample_count;
     r->seed_mode = seed_mode != RT_SEED_DEFAULT ? seed_mode
                    : (kind == RT_RENDERER_MEGAKERNEL ? RT_SEED_MEGAKERNEL : RT_SEED_WAVEFRONT);
+    r->hw_queues = hw_queues_from_env();
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
+    if (const char* e = std::getenv("RT_MEGA_CHAIN_PCT")) r->mega_chain_pct = (uint32_t)std::max(0, std::min(100000, std::atoi(e)));
     if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
@@ -1025,7 +1078,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess && prop.multiProcessorCount > 0) r->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess ||
-        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_tile_read, hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     if (kind == RT_RENDERER_WAVEFRONT) {
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
@@ -1065,6 +1118,7 @@ void rt_renderer_destroy(rt_renderer* r) {
         if (r->ev_begin) (void)hipEventDestroy(r->ev_begin);
         if (r->ev_end) (void)hipEventDestroy(r->ev_end);
         if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+        if (r->ev_tile_read) (void)hipEventDestroy(r->ev_tile_read);
         if (r->stream) (void)hipStreamDestroy(r->stream);
     }
     delete r;
@@ -1076,8 +1130,11 @@ int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     HIPCHK(hipSetDevice(r->scene->device));
     drain_streams(r, r->pending_stream); // the queues are about to be freed: nothing may be running on any of the renderer's streams
+    const TileDev old = r->tile;
     r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
-    return no_throw([&] { return alloc_tile_buffers(r); });
+    const int rc = no_throw([&] { return alloc_tile_buffers(r); });
+    if (rc != RT_OK) r->tile.rank = old.rank, r->tile.world = old.world, r->tile.strip_rows = old.strip_rows;
+    return rc;
 }
 
 int32_t rt_renderer_local_rows(const rt_renderer* r) { return r ? r->tile.local_rows : 0; }
@@ -1116,8 +1173,11 @@ int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
     if (r->kind != RT_RENDERER_WAVEFRONT) return RT_OK; // the megakernel is one launch: nothing to schedule
     HIPCHK(hipSetDevice(r->scene->device));
     drain_streams(r, r->pending_stream); // the queues are re-allocated (stream lanes, second queue, hit records, dynamic queue)
+    const rt_schedule old = r->sched;
     r->sched = *s;
-    return no_throw([&] { return alloc_tile_buffers(r); });
+    const int rc = no_throw([&] { return alloc_tile_buffers(r); });
+    if (rc != RT_OK) r->sched = old; // the buffers are gone (frames are refused), the schedule on record is the last one that worked
+    return rc;
 }
 
 int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8, rt_stats* stats) {
@@ -1398,13 +1458,16 @@ int rt_frame_gather_begin(rt_comm* c, rt_renderer* const* rs, int want_f32, int 
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev_frame, c->root_stream));
         c->frame_recorded = true;
-        if (!c->use_rccl) { // device copies read the tiles from the root stream: a renderer's next frame must not overwrite its tile before
-            for (uint32_t i = 0; i < n; ++i) {
-                HIPCHK(hipSetDevice(c->devices[i]));
-                HIPCHK(hipStreamWaitEvent(rs[i]->stream, c->ev_frame, 0));
-            }
-            HIPCHK(hipSetDevice(c->devices[0]));
+        // A renderer's next frame must not overwrite its tile before it has been read: RCCL's send sits on the renderer's own stream already;
+        // the device copies read from the root stream, so the own stream is made to wait for them. Either way an event recorded on the own
+        // stream now marks "tile read", and rt_render_frame_begin makes a CALLER's stream wait for it too.
+        for (uint32_t i = 0; i < n; ++i) {
+            HIPCHK(hipSetDevice(c->devices[i]));
+            if (!c->use_rccl) HIPCHK(hipStreamWaitEvent(rs[i]->stream, c->ev_frame, 0));
+            HIPCHK(hipEventRecord(rs[i]->ev_tile_read, rs[i]->stream));
+            rs[i]->tile_read_recorded = true;
         }
+        HIPCHK(hipSetDevice(c->devices[0]));
         return RT_OK;
     });
 }

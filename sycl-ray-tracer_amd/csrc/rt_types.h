@@ -92,7 +92,6 @@ static_assert(sizeof(MatRec) == 48, "MatRec must be 48 bytes");
 // device pointers of one scene replica
 struct SceneDev {
     const BvhNode* nodes;
-    const void* reserved;
     const uint8_t* tris; // leaf order, kTriBytes per triangle
     const ShadeRec* shade;
     const InstRec* inst;

@@ -38,6 +38,10 @@ static void usage(const char* argv0) {
 }
 
 int main(int argc, const char* argv[]) {
+    // HIP serves a process's streams from GPU_MAX_HW_QUEUES hardware queues, 4 by default: the per-bounce schedules' three stream lanes plus the
+    // frame's stream want more, and the library (which never changes the environment) would otherwise resolve them down to two lanes. This is
+    // the HOST's setting, made here before the first HIP call of the process (rt_stats.hw_queues reports what the library saw).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     uint32_t max_depth = 10, sample_count = 32, rr = 0;
     std::string scene_path = "./assets/sponza.glb", out_path = "out.png";
     bool use_wavefront = false, use_megakernel = false, quiet = false;

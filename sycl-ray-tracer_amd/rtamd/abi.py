@@ -125,6 +125,8 @@ class rt_stats(C.Structure):
         ("finish_depth", C.c_uint32),
         ("cost_ordered", C.c_uint32),
         ("kernel_ms", C.c_double * RT_K_COUNT),
+        ("hw_queues", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

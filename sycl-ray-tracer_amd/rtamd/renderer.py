@@ -105,13 +105,14 @@ class Frame:
     finish_depth: int = 0
     cost_ordered: bool = False
     kernel_ms: dict = None       # with profiling: summed launch durations per kernel family (hipEvents on the launches' own streams)
+    hw_queues: int = 0           # GPU_MAX_HW_QUEUES as the library read it (4 = HIP's default): bounds the automatic stream lanes
 
     @classmethod
     def from_stats(cls, f, b, st):
         return cls(f, b, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches), int(st.launches),
                    {name: int(st.launches_by_kernel[i]) for name, i in abi.KERNELS.items()}, int(st.stream_lanes),
                    int(st.samples_per_launch), int(st.finish_depth), bool(st.cost_ordered),
-                   {name: float(st.kernel_ms[i]) for name, i in abi.KERNELS.items()})
+                   {name: float(st.kernel_ms[i]) for name, i in abi.KERNELS.items()}, int(st.hw_queues))
 
     def stat_lines(self) -> list[str]:
         """The three lines benchmark.py scrapes (src/render_wavefront.cpp:425-427, benchmark.py:49-55)."""

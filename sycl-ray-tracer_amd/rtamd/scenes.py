@@ -952,3 +952,30 @@ SCENES = {
 
 def get_scene(name: str, **kw) -> SceneDesc:
     return SCENES[name](**kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# a generated scene as ONE file: rank 0 of a multi-process run generates it, the other ranks read it (bench.py)
+# ----------------------------------------------------------------------------------------------
+def save_scene(sd: SceneDesc, path) -> None:
+    """Every array of the description plus the materials / camera as small tables, uncompressed (9 MB of textures: writing is what
+    the other ranks wait for)."""
+    mats = sd.materials
+    np.savez(path, name=np.array(sd.name), positions=sd.positions, normals=sd.normals, uvs=sd.uvs, indices=sd.indices,
+             tri_instance=sd.tri_instance, transforms=sd.transforms, normal_mats=sd.normal_mats, inst_material=sd.inst_material,
+             textures=sd.textures, sky=sd.sky,
+             mat_type=np.array([m.type for m in mats], np.int64), mat_color=np.array([m.color for m in mats], np.float64).reshape(-1, 3),
+             mat_tex=np.array([-1 if m.tex_layer is None else m.tex_layer for m in mats], np.int64),
+             mat_emissive=np.array([m.emissive for m in mats], np.float64).reshape(-1, 3),
+             mat_rough_ior=np.array([(m.roughness, m.ior) for m in mats], np.float64).reshape(-1, 2),
+             cam=np.array([*sd.camera.position, *sd.camera.direction, sd.camera.focal_length], np.float64))
+
+
+def load_scene(path) -> SceneDesc:
+    z = np.load(path, allow_pickle=False)
+    mats = [Material(int(t), tuple(float(v) for v in c), None if int(x) < 0 else int(x), tuple(float(v) for v in e), float(ri[0]), float(ri[1]))
+            for t, c, x, e, ri in zip(z["mat_type"], z["mat_color"], z["mat_tex"], z["mat_emissive"], z["mat_rough_ior"])]
+    cam = z["cam"]
+    return SceneDesc(str(z["name"]), z["positions"], z["normals"], z["uvs"], z["indices"], z["tri_instance"], z["transforms"], z["normal_mats"],
+                     z["inst_material"], mats, z["textures"], z["sky"],
+                     CameraPose(tuple(float(v) for v in cam[0:3]), tuple(float(v) for v in cam[3:6]), float(cam[6])))

@@ -7,6 +7,10 @@ import pytest
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
+# The HOST's HIP configuration, made before anything in the test process touches HIP: eight hardware queues, so that the per-bounce
+# schedules get the three stream lanes they ask for (the library never sets this itself; test_library_loaded_after_hip_... covers a host
+# that did not)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):

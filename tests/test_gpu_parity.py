@@ -6,6 +6,11 @@ execute the same IEEE operations in the same order: DESIGN.md §3), which trivia
 tolerance of per-pixel RMSE < 1e-4. Full-size frames, which the oracle cannot finish in seconds, are
 covered by size-independent properties plus oracle spot checks of sub-tiles."""
 import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -14,6 +19,7 @@ import pytest
 from rtamd import abi, scenes
 from rtamd.renderer import Camera, MegakernelRenderer, Scene, TileComm, WavefrontRenderer, assemble_tiles
 
+REPO = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
 NO_TRI = 0xFFFFFFFF
@@ -462,6 +468,78 @@ def test_schedule_environment_shim_maps_onto_the_api(gpu_scenes, oracle, monkeyp
         assert got.kernels[kernel] == count, (env, got.kernels)
         _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"env {env}")
         r.close()
+
+
+def test_failed_reallocation_leaves_a_renderer_that_says_so(gpu_scenes, oracle, monkeypatch):
+    """rt_renderer_set_schedule / rt_renderer_set_tile free and re-allocate the tile's queues. If an allocation fails part-way (injected:
+    RT_INJECT_ALLOC_FAILURE=k fails the k-th one as out of memory) the renderer must not keep half-built lanes that the next frame would
+    launch on: the call reports RT_ERR_OOM, the schedule / tile on record stay the last ones that worked, every frame entry point
+    refuses the renderer with an error code, and a later successful call makes it whole again — same frame as before."""
+    gs = gpu_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 64, 48, 5, 2
+    cam = Camera.for_scene(sd, (w, h))
+    for cls, kind in ((WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT), (MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL)):
+        f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp)
+        r = cls(gs, (w, h), depth, spp)
+        for k in ((1, 2, 3) if cls is MegakernelRenderer else (1, 2, 3, 6, 9, 15, 27)):  # (odd: the 3-lane schedule's ~40 allocations; even: the default's ~10)
+            monkeypatch.setenv("RT_INJECT_ALLOC_FAILURE", str(k))
+            with pytest.raises(abi.RtError) as e:
+                if cls is WavefrontRenderer and k % 2:
+                    r.set_schedule(finish_depth=ALL_BOUNCES, stream_lanes=3)
+                else:
+                    r.set_tile(0, 2, 8)
+            assert e.value.status == abi.RT_ERR_OOM, e.value
+            monkeypatch.delenv("RT_INJECT_ALLOC_FAILURE")
+            sc = r.get_schedule()
+            assert sc.finish_depth == 0 and sc.stream_lanes == 0  # the schedule on record: the last one that worked
+            for call in (lambda: r.render_frame(cam), lambda: r.begin_frame(cam)):
+                with pytest.raises(abi.RtError) as e:
+                    call()
+                assert e.value.status == abi.RT_ERR_INVALID and "no buffers" in str(e.value)
+            r.set_tile(0, 1, 8)  # whole again
+            got = r.render_frame(cam)
+            _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{cls.__name__} after failure {k}")
+        r.close()
+
+
+def test_library_loaded_after_hip_is_up_resolves_its_stream_lanes(gpu_scenes, oracle):
+    """A host that initialised HIP before it loaded the library and never set GPU_MAX_HW_QUEUES has HIP's four hardware queues. The library
+    does not touch the environment (round 3 did, from a constructor): it reads the host's setting, resolves the per-bounce schedules'
+    automatic three stream lanes down to two (lanes + 2 <= queues), says so in rt_stats, and renders the same frame. Run in a child process
+    (this one has its queue count fixed by conftest.py): torch brings HIP up first, THEN the library is loaded."""
+    gs = gpu_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 96, 64, 6, 4
+    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_WAVEFRONT, depth, spp)
+    code = f"""
+import hashlib, json, sys
+sys.path.insert(0, {str(REPO)!r}); sys.path.insert(0, {str(REPO / 'sycl-ray-tracer_amd')!r})
+import torch
+torch.cuda.init(); x = torch.zeros(4, device='cuda'); torch.cuda.synchronize()   # HIP is up, with its default queues
+from rtamd import abi, scenes
+from rtamd.renderer import Camera, Scene, WavefrontRenderer
+sd = scenes.get_scene('cornell'); sc = Scene(sd, 0); cam = Camera.for_scene(sd, ({w}, {h}))
+out = {{}}
+for name, kw in (('split', dict(finish_depth=abi.RT_SCHED_ALL_BOUNCES)), ('fused', dict(finish_depth=abi.RT_SCHED_ALL_BOUNCES, fused_bounce=True)),
+                 ('asked3', dict(finish_depth=abi.RT_SCHED_ALL_BOUNCES, stream_lanes=3))):
+    r = WavefrontRenderer(sc, ({w}, {h}), {depth}, {spp}); r.set_schedule(**kw)
+    fr = r.render_frame(cam)
+    out[name] = dict(lanes=fr.stream_lanes, queues=fr.hw_queues, rays=fr.rays, f32=hashlib.sha1(fr.rgba_f32.tobytes()).hexdigest(),
+                     u8=hashlib.sha1(fr.rgba_u8.tobytes()).hexdigest(), extend=fr.kernels['wf_extend'], shoot=fr.kernels['wf_shoot'])
+    r.close()
+print('RESULT ' + json.dumps(out))
+"""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    want_f32, want_u8 = hashlib.sha1(f.tobytes()).hexdigest(), hashlib.sha1(b.tobytes()).hexdigest()
+    for name, o in out.items():
+        assert o["queues"] == 4, (name, o)                       # what the library saw: HIP's default
+        assert o["lanes"] == (3 if name == "asked3" else 2), (name, o)  # automatic: resolved down; explicit: the caller's business
+        assert (o["rays"], o["f32"], o["u8"]) == (rays, want_f32, want_u8), (name, o)
+    assert out["split"]["extend"] == 2 * spp * depth and out["fused"]["shoot"] == 2 * spp * depth
 
 
 @pytest.mark.parametrize("env", [{"RT_WF_SHOOT_TAIL": "0"}, {"RT_WF_SHOOT_TAIL": "0", "RT_WF_SHOOT_CHUNK": "32"}, {"RT_WF_SHOOT_STATIC_PCT": "0", "RT_WF_SHOOT_CHUNK": "16"},

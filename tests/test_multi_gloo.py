@@ -88,7 +88,8 @@ def test_bench_launches_its_own_ranks(tmp_path, oracle, world):
         np.save(tmp_path / f"tile_{rank}.npy", f)
     full, _, _ = sc.render(cam, 1, 4, 2)
     out = tmp_path / "frame.npy"
-    p = _bench(["--gpus", world, "--steps", 3, "--warmup", 1, "--width", w, "--height", h, "--backend", "gloo", "--rehearsal-tiles", tmp_path, "--dump-frame", out])
+    p = _bench(["--gpus", world, "--steps", 3, "--warmup", 1, "--width", w, "--height", h, "--backend", "gloo", "--rehearsal-tiles", tmp_path, "--dump-frame", out,
+                "--detail", 1])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -96,6 +97,11 @@ def test_bench_launches_its_own_ranks(tmp_path, oracle, world):
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and d["steps"] == 3 and d["warmup"] == 1
     assert len(d["per_rank_ms"]) == world and all(ms > 0 for ms in d["per_rank_ms"]) and d["gather_ms"] > 0
     assert d["scaling"] == "strong" and d["ms_per_step"] > 0
+    # the shared-scene path: generated once by rank 0, read from its file by the others — every rank holds the same bytes, and every rank
+    # reports what its setup cost before the timed region
+    assert len(d["scene_digests"]) == world and len(set(d["scene_digests"])) == 1, d["scene_digests"]
+    assert len(d["setup_s_per_rank"]) == world and all(r["scene_s"] > 0 for r in d["setup_s_per_rank"])
+    # (3 frames through 3 strip buffers with the exchange of frame i overlapping frame i + 1: the last frame's gather is the dumped one)
     np.testing.assert_array_equal(np.load(out), full)
 
 
