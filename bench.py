@@ -117,8 +117,24 @@ def launch_ranks(args) -> int:
     return p.returncode
 
 
+_JSON_FD = None
+
+
+def emit(line: str) -> None:
+    """The ONE line of the contract, on the process's real stdout."""
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def main() -> int:
     args = parse_args()
+    # stdout carries the JSON line and nothing else: RCCL prints a version banner to stdout when its first communicator comes up, and
+    # libraries may say more. File descriptor 1 is pointed at stderr for the life of the process; emit() writes to the saved one.
+    global _JSON_FD
+    launcher = "WORLD_SIZE" not in os.environ and args.gpus > 1  # (the launcher's child ranks do this themselves)
+    if _JSON_FD is None and not args.pmc_child and not launcher:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
     # HIP serves streams from GPU_MAX_HW_QUEUES hardware queues (4 by default): the per-bounce renderers' three lane streams, the frame's stream
     # and torch's own would share them and run one after the other (rt_mi355x.hip: wf_stream_lanes). Before torch or the library touch HIP:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -358,7 +374,8 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(sd, W, H, args.depth, args.cpu_spp, best["renderer"])
         if args.dump_frame:
             np.save(args.dump_frame, fgs[last_buffer[0]].frame.cpu().numpy())
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        emit(json.dumps(out))
     if scene is not None:
         scene.close()
     if use_dist:

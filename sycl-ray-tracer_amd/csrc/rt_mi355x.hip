@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -166,7 +168,8 @@ struct rt_renderer {
         std::vector<uint32_t> h_counts;
         unsigned long long* d_extra = nullptr; // per launch: rays k_wf_finish traced beyond its queue's length; [spp]: the dynamic queue's error word
         std::vector<unsigned long long> h_extra;
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr; // from the device's lane-stream pool (lane_stream_of) unless stream_owned
+        bool stream_owned = false;
         hipEvent_t ev_done = nullptr;
         std::vector<hipEvent_t> ev_pool;
         size_t n_hot = 0;
@@ -244,7 +247,7 @@ void free_tile_buffers(rt_renderer* r) {
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.stream && L.stream_owned) (void)hipStreamDestroy(L.stream);
     }
     r->lanes.clear();
 }
@@ -341,6 +344,47 @@ uint32_t wf_chunk(const rt_renderer* r, uint32_t n_local) {
     return (uint32_t)std::max<uint64_t>(1, c);
 }
 
+// The stream lanes' HIP streams: a pool of THREE per device, created by the first renderer on the device and shared by every renderer
+// there; lane k runs on pool stream k (a lane beyond the pool — an explicit stream_lanes > 3 — gets a stream of its renderer's own).
+// Rounds 1-3 created a stream per renderer and lane. Which hardware queue a stream lands on, and how well queues run side by side, turned
+// out to depend on every stream the process had created before (measured in round 4 with bench.py's four renderers one after the other and a
+// torch process group up; the split per-bounce pipeline, three lanes, ms per 64-spp frame):
+//     a stream per renderer and lane, default priority             313   (191 when that renderer was the process's first)
+//     ... at the high stream priority (a queue pool of their own)   221
+//     this pool, streams created once, queues made at first use     191   in every order of the renderers
+//     the same pool with a FOURTH stream that had been used once    222   (an idle fourth queue at that priority costs 16 %)
+// So: few streams, created once, at a priority level the host framework's streams (torch's, RCCL's) do not use. HIP keeps a hardware-queue
+// pool per priority level and makes a stream's queue at its first submission. (Two renderers of one device with per-bounce frames in
+// flight at the same time share the lanes' streams: lane k of one frame queues behind lane k of the other. The one-launch schedule does
+// not use lane streams.)
+constexpr uint32_t kLanePool = 3;
+hipError_t lane_stream_of(int device, uint32_t k, hipStream_t* out, bool* owned) {
+    static std::mutex mu;
+    static std::map<int, std::vector<hipStream_t>> pools;
+    int prio_lo = 0, prio_hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (e != hipSuccess) return e;
+    if (k >= kLanePool) { // beyond the pool (explicit stream_lanes > 4): a stream of the renderer's own
+        *owned = true;
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_hi);
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<hipStream_t>& pool = pools[device];
+    if (pool.empty()) {
+        std::vector<hipStream_t> fresh(kLanePool, nullptr);
+        for (uint32_t i = 0; i < kLanePool; ++i) {
+            e = hipStreamCreateWithPriority(&fresh[i], hipStreamNonBlocking, prio_hi);
+            if (e != hipSuccess) {
+                for (uint32_t j = 0; j < i; ++j) (void)hipStreamDestroy(fresh[j]);
+                return e;
+            }
+        }
+        pool = fresh; // (lives as long as the process: a handful of idle streams)
+    }
+    *out = pool[k], *owned = false;
+    return hipSuccess;
+}
+
 int alloc_tile_buffers_impl(rt_renderer* r) {
     free_tile_buffers(r);
     // test hook: RT_INJECT_ALLOC_FAILURE=k makes the k-th device allocation of this call fail as if the device were out of memory
@@ -408,7 +452,7 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
                 HIPCHK(dalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
                 HIPCHK(dalloc((void**)&L.d_rq_ctl, 80 * 4));
             }
-            HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            HIPCHK(lane_stream_of(r->scene->device, k, &L.stream, &L.stream_owned));
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
     }
@@ -1074,6 +1118,11 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         rt_renderer_destroy(r);
         return code;
     };
+    { // the device's lane-stream pool is set up by the FIRST renderer of either kind (see lane_stream_of: early, and in one burst)
+        hipStream_t s0 = nullptr;
+        bool owned = false;
+        if (lane_stream_of(scene->device, 0, &s0, &owned) != hipSuccess) return bail(fail(RT_ERR_HIP, "cannot create the stream-lane pool"));
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess && prop.multiProcessorCount > 0) r->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));

@@ -3,9 +3,26 @@
 // restart intervals. Output is RGBA8, as the reference's loader gets it from
 // stbi_load_from_memory(bytes, size, &w, &h, &comp, 4) (deps/include/tiny_gltf.h:2603-2634 of the reference).
 //
-// Every step with a numerical choice follows the decoder the reference uses (stb_image v2.x, itself "derived from
-// jidctint"), so that the texels are the same — checked bit for bit against the reference's own decoder, built from
-// the reference's files, in tests/test_ref_stb.py:
+// ATTRIBUTION. This file is DERIVED FROM stb_image v2.29 by Sean Barrett and contributors (http://nothings.org/stb; the third-party
+// header the reference vendors as deps/include/stb_image.h and its loader calls): the Huffman table construction and fast-path lookup,
+// the baseline and progressive (DC / AC, first and refinement scans) block decoders, the islow inverse DCT "derived from jidctint", the
+// triangle-filter chroma upsampling and the fixed-point YCbCr conversion are stb_image's algorithms, re-typed here as C++ with exceptions
+// and bounds checks, with its control flow, field names and error strings largely kept. stb_image is dual-licensed: MIT (Copyright (c)
+// 2017 Sean Barrett) or public domain (unlicense.org); the MIT notice follows as that licence requires.
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation files
+//   (the "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy, modify, merge,
+//   publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is furnished to do
+//   so, subject to the following conditions: The above copyright notice and this permission notice shall be included in all copies or
+//   substantial portions of the Software. THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING
+//   BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE
+//   AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// It is third-party code outside the hot path (the loader; SURVEY §2 row 18 lists deps/ as third party). Why a
+// derived decoder and not a clean-room one: the texels must be the ones the reference's loader produces, and every step with a numerical
+// choice has to be stb_image's for that — checked bit for bit against the reference's own copy of stb_image, compiled where it lies
+// (by the test suite), in tests/test_ref_stb.py:
 //   * inverse DCT: the Loeffler-Ligtenberg-Moschytz "islow" factorisation with 12-bit constants, two extra bits kept
 //     after the column pass, +128 level shift folded into the final rounding;
 //   * chroma upsampling: the 3:1 "triangle" filter horizontally, vertically or both ((3a+b+2)>>2, (9a+3b+3c+d+8)>>4),
