@@ -344,41 +344,17 @@ RT_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 struct WaveStats {
     uint32_t inner_steps = 0, inner_lanes = 0, leaf_steps = 0, leaf_lanes = 0;
     uint32_t shade_rounds = 0, shade_lanes = 0, live_lane_steps = 0, top_lanes = 0;
-    // where a step's time goes (shader clock): inner step = fetch (node words arrived) + test (boxes, sort) + stack (pushes, pop arrived);
-    // leaf step = fetch (first record arrived) + the rest
-    unsigned long long t_in_fetch = 0, t_in_test = 0, t_in_stack = 0, t_lf_fetch = 0, t_lf_rest = 0;
 };
-// STATS builds: a time stamp that the compiler cannot move across the values named (an empty dependence on them), after everything
-// outstanding has arrived
-RT_DEV long long stamp(int32_t& a) {
-    long long t;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a) : : "memory");
-    return t;
-}
-RT_DEV long long stamp(float& a, float& b, float& c, float& d) {
-    long long t;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
-    return t;
-}
-RT_DEV long long stamp(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    long long t;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
-    return t;
-}
-
 // inner step: fetch the 64-byte BVH4 node, decode and test its four quantised child boxes, descend into
 // the nearest hit child and push the other hits far-to-near.
 //   t(plane q) = (origin + q*s - o) * inv = q * (s*inv) + (origin*inv - o*inv)
 // The near/far plane words are picked once per axis from the ray's direction sign, so no per-child
 // min/max pairing is needed.
 RT_DEV TravSigns trav_signs(const Trav& T) { return TravSigns{lanes(T.ix < 0.0f), lanes(T.iy < 0.0f), lanes(T.iz < 0.0f)}; }
-template <bool TIMED = false>
-RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg, WaveStats* ws = nullptr) {
+RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg) {
     const float inf = __builtin_huge_valf();
     float k0, k1, k2, k3;
     u32x4 w0, w1, w2, chw;
-    long long t0 = 0, t1 = 0, t2 = 0;
-    if (TIMED) t0 = stamp(T.cur);
     if (T.cur < top.count * 64) { // top of the tree: LDS, 16 bytes per node and plane
         const uint32_t o = (uint32_t)T.cur >> 2;
         w0 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w0 + o), w1 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w1 + o);
@@ -387,7 +363,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         const u32x4* np = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)T.cur);
         w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
     }
-    if (TIMED) t1 = stamp(w0, w1, w2, chw), ws->t_in_fetch += (unsigned long long)(t1 - t0);
     const float ax = __uint_as_float(w0.w) * T.ix;
     const float ay = __uint_as_float(w2.z) * T.iy;
     const float az = __uint_as_float(w2.w) * T.iz;
@@ -434,7 +409,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     RT_CE(k0, c0, k2, c2)
     // with fewer than five comparators the hits are no longer a sorted prefix of (k1, k2, k3): each is tested on its own below
 #undef RT_CE
-    if (TIMED) t2 = stamp(k0, k1, k2, k3), ws->t_in_test += (unsigned long long)(t2 - t1);
     const bool descend = k0 < inf;
     if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
         if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
@@ -449,7 +423,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         if (descend) T.cur = c0;
         else trav_pop(T, stack);
     }
-    if (TIMED) ws->t_in_stack += (unsigned long long)(stamp(T.cur) - t2);
 }
 
 // leaf step. BATCH = false: ONE triangle of the leaf per step, then the next one or pop (rt_intersect_batch).
@@ -457,17 +430,14 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 // the wave's vote, so every extra leaf step costs it several iterations; the next record is fetched while the current
 // one is tested (two in flight, 24 VGPRs), the loop bound is the wave's largest leaf (uniform branch). Measured on the
 // megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
-template <bool BATCH, bool TIMED = false>
-RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack, WaveStats* ws = nullptr) {
+template <bool BATCH>
+RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
-        long long t0 = 0, t1 = 0;
-        if (TIMED) t0 = stamp(T.cur);
         const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
         float4 a = tri_ld4(p4), b = tri_ld4(p4 + 16);
         float2 c = tri_ld2(p4 + 32);
-        if (TIMED) t1 = stamp(a.x, b.x, c.x, c.y), ws->t_lf_fetch += (unsigned long long)(t1 - t0);
         uint32_t k = 1;
         for (; k < (uint32_t)kMaxLeafTris; ++k) {
             if (__ballot(k <= rem) == 0ull) break;
@@ -480,7 +450,6 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack, WaveSt
         if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
         if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
         else trav_pop(T, stack);
-        if (TIMED) ws->t_lf_rest += (unsigned long long)(stamp(T.cur) - t1);
     } else {
         tri_test(S.tris + (size_t)first * kTriBytes, T.o, T.d, T.best);
         if (rem) T.cur = ~(int32_t)(((first + 1u) << 2) | (rem - 1u));
@@ -498,35 +467,12 @@ RT_DEV uint32_t trav_step_wave(const SceneDev& S, Trav& T, const TravStack& stac
     // many iterations as the vote goes against it (plain majority: -1.2 %; EXPERIMENTS.md)
     if (ni * 3u >= nl * 4u && !(LEAF_BATCH && nl >= 64u)) {
         if (STATS && ni) ws->inner_steps++, ws->inner_lanes += ni, ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * 64));
-        if (inner) trav_inner<STATS>(S, T, stack, top, sg, ws);
+        if (inner) trav_inner(S, T, stack, top, sg);
     } else {
         if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(__ballot(leaf));
-        if (leaf) trav_leaf<LEAF_BATCH, STATS>(S, T, stack, ws);
+        if (leaf) trav_leaf<LEAF_BATCH>(S, T, stack);
     }
     return ni + nl;
-}
-
-// The chain regime's step (round 4). Where a tile has no more pixels than the chip has lanes, every pixel is in flight from the first
-// microsecond and the frame takes as long as its slowest pixel CHAIN: what counts is how many wave iterations a ray needs, not how many
-// instructions the SIMD issues (measured on 1/8 of the 1080p frame: VALU busy 0.69 against 0.86 on the full frame, and halving the waves
-// per SIMD shortens a wave's step by 9 % only: a step is a dependent chain of one fetch and ~130 instructions). With the vote above a ray
-// of ~20 steps of its own takes ~44 wave iterations. Here an iteration runs BOTH classes: every lane at an inner node takes its inner
-// step, then every lane at a leaf — those that have just arrived there included — tests its leaf. Per lane the same steps in the same
-// order as with the vote: nothing a pixel computes changes.
-template <bool STATS = false>
-RT_DEV void trav_step_both(const SceneDev& S, Trav& T, const TravStack& stack, const TopTree& top, const TravSigns& sg, WaveStats* ws = nullptr) {
-    const bool inner = T.cur >= 0;
-    const lmask im = lanes(inner);
-    if (im != 0ull) {
-        if (STATS) ws->inner_steps++, ws->inner_lanes += (uint32_t)__popcll(im), ws->top_lanes += (uint32_t)__popcll(__ballot(inner && T.cur < kTopNodes * 64));
-        if (inner) trav_inner<STATS>(S, T, stack, top, sg, ws);
-    }
-    const bool leaf = T.cur < 0 && T.cur != kTravDone;
-    const lmask lm = lanes(leaf);
-    if (lm != 0ull) {
-        if (STATS) ws->leaf_steps++, ws->leaf_lanes += (uint32_t)__popcll(lm);
-        if (leaf) trav_leaf<true, STATS>(S, T, stack, ws);
-    }
 }
 
 // run to completion (rt_intersect_batch; lanes that finish early wait for the wave)

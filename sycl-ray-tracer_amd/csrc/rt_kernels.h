@@ -8,7 +8,6 @@
 //   k_wf_finish    == K4 + K5 for every bounce of a path (and, by default, K3 for every sample after a pixel's first): the
 //                     WavefrontRenderer's default schedule, one launch per frame (:222-354, 396-417)
 //   k_wf_resolve   == K6 convert_image_to_srgb + K7 write_image (:377-390, src/util.hpp:16-23)
-//   (rt_kernel_ts.h: k_megakernel_ts, an experiment)
 #pragma once
 #include "rt_device.h"
 
@@ -113,18 +112,6 @@ constexpr uint32_t kMegaBlock = 512;   // threads per workgroup: 8 independent w
 constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compiled for (80 VGPRs): 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
 constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
 constexpr uint32_t kMegaShadePct = 75; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
-#ifndef RT_CHAIN_UNROLL
-#define RT_CHAIN_UNROLL 3
-#endif
-#ifndef RT_CHAIN_WAVES
-#define RT_CHAIN_WAVES 4
-#endif
-#ifndef RT_CHAIN_BOTH
-#define RT_CHAIN_BOTH 0
-#endif
-constexpr uint32_t kChainWaves = RT_CHAIN_WAVES; // the chain regime's instantiation: a tile of one pixel generation fills 4 waves per SIMD at most (128 VGPRs)
-constexpr bool kChainBoth = RT_CHAIN_BOTH != 0;
-constexpr int kChainUnroll = RT_CHAIN_UNROLL; // ... in the chain regime's instantiation (an iteration there is an inner AND a leaf step)
 constexpr uint32_t kMegaRefill = 1;    // idle lanes that trigger a pixel fetch — as the STARTING value of RefillPolicy:
 // A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
 // part, and a lane that waits for company is idle: with lanes falling idle at a rate L per unit of wave time, refilling at T idle lanes
@@ -156,9 +143,8 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
         }
     }
 };
-// CHAIN: the instantiation for tiles of (about) one pixel generation: both step kinds per iteration (trav_step_both)
-template <bool STATS, bool CHAIN = false>
-__global__ void __launch_bounds__(kMegaBlock, CHAIN ? kChainWaves : kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
+template <bool STATS>
+__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
                                                     uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
@@ -252,13 +238,11 @@ __global__ void __launch_bounds__(kMegaBlock, CHAIN ? kChainWaves : kMegaWaves) 
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * kMegaShadePct) break;
             if (STATS) ws.live_lane_steps += n_live;
             refill.stepped();
-            if (CHAIN && kChainBoth) trav_step_both<STATS>(S, T, stack, top, sg, &ws);
-            else (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
 #pragma unroll
-            for (int k = 1; k < (CHAIN ? kChainUnroll : kMegaUnroll); ++k) { // the exit tests are checked every kMegaUnroll steps
+            for (int k = 1; k < kMegaUnroll; ++k) { // the exit tests are checked every kMegaUnroll steps
                 if (STATS) ws.live_lane_steps += n_live;
-                if (CHAIN && kChainBoth) trav_step_both<STATS>(S, T, stack, top, sg, &ws);
-                else (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
@@ -313,8 +297,6 @@ __global__ void __launch_bounds__(kMegaBlock, CHAIN ? kChainWaves : kMegaWaves) 
         atomicMin(stats_out + 13, wall_begin);
         if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
         atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
-        atomicAdd(stats_out + 16, ws.t_in_fetch), atomicAdd(stats_out + 17, ws.t_in_test), atomicAdd(stats_out + 18, ws.t_in_stack);
-        atomicAdd(stats_out + 19, ws.t_lf_fetch), atomicAdd(stats_out + 20, ws.t_lf_rest);
     }
 }
 

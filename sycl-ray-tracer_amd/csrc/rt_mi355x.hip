@@ -225,7 +225,6 @@ struct rt_renderer {
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
     uint32_t hw_queues = 4; // GPU_MAX_HW_QUEUES as the host had set it when the renderer was created (4 = HIP's default): bounds the automatic stream lanes
     uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
-    uint32_t mega_chain_pct = 100; // tiles of up to this share of the chip's resident lanes render with k_megakernel<.., CHAIN> (RT_MEGA_CHAIN_PCT; 0 = never)
 };
 
 namespace {
@@ -716,15 +715,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         // (in the chain regime — fewer tiles than wave slots — 64 pixels on 4,050 waves beat 42 pixels on all 6,144: 29.5 against 33.7 ms)
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
-        // the chain regime's instantiation (rt_device.h: trav_step_both) where the tile is about one generation of pixels: at most
-        // mega_chain_pct per cent of the lanes the chip holds
-        const bool chain = (uint64_t)tiles_x * tiles_y * 64u * 100u <= (uint64_t)r->mega_chain_pct * (uint64_t)r->n_cus * 4u * kMegaWaves * 64u;
         const uint32_t pad = r->mega_lds_pad;
         if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
         }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
@@ -735,17 +729,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
             HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, 9 * sizeof(unsigned long long), st));
-            if (chain)
-                hipLaunchKernelGGL((k_megakernel<true, true>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                                   r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
-            else
-                hipLaunchKernelGGL((k_megakernel<true, false>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                                   r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
-        } else if (chain) {
-            hipLaunchKernelGGL((k_megakernel<false, true>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
         } else {
-            hipLaunchKernelGGL((k_megakernel<false, false>), dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
                                r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
         }
         HIPCHK(hipGetLastError());
@@ -901,9 +888,6 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                          "%.0f cycles per traversal step, %.0f per shade round\n",
                          h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
                          (h[0] + h[2]) ? (double)h[11] / (h[0] + h[2]) : 0.0, h[4] ? (double)h[12] / h[4] : 0.0);
-        if (h[16] && h[0] && h[2])
-            std::fprintf(stderr, "[rt stats] cycles per inner step: fetch %.0f, box tests + sort %.0f, pushes / pop %.0f | per leaf step: fetch %.0f, tests + pop %.0f\n",
-                         (double)h[16] / h[0], (double)h[17] / h[0], (double)h[18] / h[0], (double)h[19] / h[2], (double)h[20] / h[2]);
         if (h[10] && h[15] > h[13] && h[14] != ~0ull)
             std::fprintf(stderr, "[rt stats] frame timeline: %.2f ms in all, pixel queue empty after %.2f ms, drain %.2f ms (%.1f%%)\n",
                          (h[15] - h[13]) * 1e-5, (h[14] - h[13]) * 1e-5, (h[15] - h[14]) * 1e-5, 100.0 * (h[15] - h[14]) / (h[15] - h[13]));
@@ -1112,7 +1096,6 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
-    if (const char* e = std::getenv("RT_MEGA_CHAIN_PCT")) r->mega_chain_pct = (uint32_t)std::max(0, std::min(100000, std::atoi(e)));
     if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
