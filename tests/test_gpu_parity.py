@@ -231,16 +231,26 @@ def test_gpu_built_lbvh_is_valid_and_fast(gpu_scenes, scene_cache):
     passes the host's structural check; the build beats the host SAH build."""
     import time
     sd = scene_cache("atrium", detail=4)
-    t0 = time.perf_counter()
-    g = Scene(sd, 0, abi.RT_BVH_LBVH_GPU)
-    t_gpu = time.perf_counter() - t0
+    Scene(sd, 0, abi.RT_BVH_LBVH_GPU).close()  # (first use: rocPRIM's kernels are loaded, the device allocator warms up)
+
+    def best_of_three(bvh):
+        best, sc = None, None
+        for _ in range(3):
+            if sc is not None:
+                sc.close()
+            t0 = time.perf_counter()
+            sc = Scene(sd, 0, bvh)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, sc
+
+    t_gpu, g = best_of_three(abi.RT_BVH_LBVH_GPU)
     g.check_bvh()
     info = g.info()
     assert info.n_triangles == sd.n_triangles and info.max_leaf_tris == 1 and info.n_nodes > sd.n_triangles // 8
-    t0 = time.perf_counter()
-    h = Scene(sd, 0, abi.RT_BVH_SAH)
-    t_host = time.perf_counter() - t0
+    t_host, h = best_of_three(abi.RT_BVH_SAH)
     print(f"scene create: GPU LBVH {t_gpu*1e3:.1f} ms, host SAH {t_host*1e3:.1f} ms")
+    assert t_gpu < t_host, f"the device build ({t_gpu*1e3:.1f} ms) should beat the host SAH build ({t_host*1e3:.1f} ms): measured 60 vs 152 ms"
     g.close(), h.close()
     for small in ("triangle", "cube", "empty"):  # fewer than 8 triangles: served by the host builder
         s2 = Scene(scene_cache(small), 0, abi.RT_BVH_LBVH_GPU)
