@@ -20,7 +20,6 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
-#include "rt_kernel_mega2.h"
 #include "scene_build.h"
 
 using namespace rt;
@@ -226,7 +225,6 @@ struct rt_renderer {
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
     uint32_t hw_queues = 4; // GPU_MAX_HW_QUEUES as the host had set it when the renderer was created (4 = HIP's default): bounds the automatic stream lanes
     uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
-    int mega2 = -1; // k_megakernel2 (two pixel contexts per lane): -1 where it applies (tiles of more than two pixel generations), 0 never, 1 wherever it can run (RT_MEGA2)
 };
 
 namespace {
@@ -725,23 +723,8 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
         HIPCHK(hipEventRecord(e0, st));
-        // k_megakernel2: two pixel contexts per lane, five waves per SIMD. Its packed fields hold 16 bits each; it pays where lanes refill
-        // several times over (more than two generations of pixels for ITS lanes), and the frame's last generation is single-context anyway
-        constexpr uint32_t m2_wpb = kMega2Block / 64;
-        const uint32_t m2_grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + m2_wpb - 1u) / m2_wpb, (uint32_t)r->n_cus * 4u * kMega2Waves / m2_wpb));
-        const bool m2_can = r->width < 65536 && r->height < 65536 && r->spp < 65536u && r->max_depth < 65536u && r->max_depth > 0;
-        const bool m2 = m2_can && (r->mega2 > 0 || (r->mega2 < 0 && (uint64_t)tiles_x * tiles_y * 64u > 2ull * m2_grid * kMega2Block));
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
-        } else if (m2) {
-            if (r->d_stats) {
-                HIPCHK(hipMemsetAsync(r->d_stats, 0, 24 * sizeof(unsigned long long), st));
-                hipLaunchKernelGGL(k_megakernel2<true>, dim3(m2_grid), dim3(kMega2Block), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode, r->rr_start,
-                                   d_f32, d_u8, r->d_ray_counter, r->d_stats);
-            } else {
-                hipLaunchKernelGGL(k_megakernel2<false>, dim3(m2_grid), dim3(kMega2Block), 0, st, S, c, r->tile, r->max_depth, r->spp, r->seed_mode, r->rr_start,
-                                   d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
-            }
         } else if (r->d_stats) {
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
@@ -1113,7 +1096,6 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
     if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
-    if (const char* e = std::getenv("RT_MEGA2")) r->mega2 = std::atoi(e) > 0 ? 1 : (std::atoi(e) == 0 ? 0 : -1);
     if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
