@@ -537,7 +537,7 @@ def binding_of(c, rays):
     8-cycle transcendentals), SQ_ACTIVE_INST_VALU2 the units that were issued as the SECOND instruction of a quad-cycle (gfx950 issues a
     full-rate instruction — fma / mul / add / mov / and / or / xor / add_u32 / lshr — of one wave beside any instruction of another
     wave); their difference is the number of quad-cycles in which the SIMD's vector ALU issued. Pinned on known instruction streams:
-    scripts/valu_calib2.hip, profiles/r03_valu_calibration2.json (0.94-0.99 on 100 %-VALU streams of every class and mix)."""
+    profiles/r03_valu_calibration2.json (0.94-0.99 on 100 %-VALU streams of every class and mix)."""
     cycles = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
     n, a, a2 = c["SQ_INSTS_VALU"], c["SQ_ACTIVE_INST_VALU"], c["SQ_ACTIVE_INST_VALU2"]
     busy = 4.0 * (a - a2) / (N_SIMDS * cycles)
@@ -571,10 +571,10 @@ def attach_pmc(out, args):
         except Exception as e:  # no rocprofv3 / no counter access here: say so and use the committed profile of the same command
             source = f"live rocprofv3 --pmc unavailable ({str(e)[:160]}); "
     if c is None:
-        prof = REPO / "profiles" / "r03_pmc_bench.json"
+        prof = REPO / "profiles" / "r04_pmc_bench.json"
         if prof.exists():
             c = {k: v for k, v in json.loads(prof.read_text()).items() if isinstance(v, dict)}
-            source = (source or "") + "committed profiles/r03_pmc_bench.json (same command: scripts/final_profile.sh)"
+            source = (source or "") + "committed profiles/r04_pmc_bench.json (same command: scripts/final_profile.sh)"
     for name in want:
         roof = out["renderers"][name]["roofline"]
         rays = out["renderers"][name]["rays_per_frame"]

@@ -1,26 +1,48 @@
 #!/bin/bash
-# Round-end evidence (run on the GPU box from the repo root; outputs under gpurun_out/r02/final, copied into profiles/ by scripts/collect_profiles.py):
-#   1. the VALU calibration with the CURRENT kernels' instruction mixes (scripts/gen_valu_mix.py must have been run on the current build)
-#   2. the default bench line (which measures traffic + the VALU-issue bound itself, in child processes under rocprofv3 --pmc)
-#   3. the same command under rocprofv3 --kernel-trace --stats (average launch duration of the dominant kernels)
-#   4. PMC passes of one frame per renderer at the bench configuration (the fallback file bench.py reads when rocprofv3 is not usable)
+# Everything committed under profiles/r04_* (GPU box, repo root; outputs under gpurun_out/r04/final, copied into profiles/ by
+# `python3 scripts/final_profile.sh collect` ... see the end of this file):
+#   1. the default bench line as the driver runs it (bench.py measures traffic + VALU busy itself, child processes under rocprofv3 --pmc)
+#   2. the same command under rocprofv3 --kernel-trace --stats (mean launch duration of the dominant kernels; no PMC, no CPU leg)
+#   3. the wavefront renderer's schedules at 64 spp, BASELINE's configurations, tile scaling (both renderers)
+#   4. counters of the megakernel on 1/8 of the frame against the full frame (what binds the chain regime)
+#   5. wave-level step statistics and frame timelines (RT_KERNEL_STATS=1), one frame and two frames in flight
+#   6. the SAH leaf criterion's traversal weight; the per-bounce pipeline behind other renderers with a process group up (stream pool)
+# usage: bash scripts/final_profile.sh [part ...]   (parts: bench ktrace tables tilepmc stats misc; default: all)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02/final; mkdir -p $out
-bash scripts/valu_calib.sh > $out/calib.log 2>&1
-echo calib done
-RT_KERNEL_STATS=1 python3 scripts/quick_bench.py 8 mega > $out/stats.log 2>&1
-python3 scripts/config_table.py > $out/config_table.txt 2>&1
-python3 scripts/tile_scaling.py 64 "" 1,2,4,8 > $out/tile_scaling.txt 2>&1
-echo stats done
-timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
-echo bench done
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-live-pmc > $out/bench_under_rocprof.json 2> $out/kt.err
-echo ktrace done
-for rend in megakernel wavefront; do
-  for pass in "fetch FETCH_SIZE TCC_HIT_sum" "write WRITE_SIZE TCC_MISS_sum" "valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" "wave SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU" "lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD"; do
-    set -- $pass; tag=$1; shift
-    timeout -k 5 200 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_${rend}_$tag -- python3 bench.py --pmc-child --renderer $rend > $out/pmc_${rend}_$tag.log 2>&1
-    echo "pmc $rend $tag rc=$?"
-  done
-done
+export GPU_MAX_HW_QUEUES=8
+out=gpurun_out/r04/final; mkdir -p $out
+parts=${@:-bench ktrace tables tilepmc stats misc}
+for part in $parts; do case $part in
+bench)
+  timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 --dump-pmc $out/pmc_bench.json > $out/bench.json 2> $out/bench.err
+  echo bench done ;;
+ktrace)
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-pipelined > $out/bench_under_rocprof.json 2> $out/kt.err
+  echo ktrace done ;;
+tables)
+  python3 scripts/schedule_probe.py 64 > $out/schedules_64spp.txt 2>&1
+  python3 scripts/config_table.py > $out/config_table.txt 2>&1
+  python3 scripts/tile_scaling.py 64 "" 1,2,4,8 > $out/tile_scaling.txt 2>&1
+  echo tables done ;;
+tilepmc)
+  bash scripts/tile_pmc.sh final mega "8 1" > $out/tile_pmc.txt 2>&1
+  echo tilepmc done ;;
+stats)
+  RT_KERNEL_STATS=1 python3 scripts/tile_scaling.py 64 mega 1,8 2>&1 | grep -E "rt stats|Renderer" | tail -8 > $out/stats.log
+  RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
+  echo stats done ;;
+misc)
+  for C in 1.0 1.5 1.9 2.5; do
+    echo "== RT_SAH_TRAV_COST=$C"
+    RT_SAH_TRAV_COST=$C RT_KERNEL_STATS=1 python3 scripts/quick_bench.py 16 mega 2>&1 | grep -E "per ray" | tail -1 | cut -c1-300
+    RT_SAH_TRAV_COST=$C python3 scripts/quick_bench.py 16 mega 2>&1 | grep Mrays
+  done > $out/sah_cost.txt 2>&1
+  for FD in 0 1; do
+    echo "== bench.py, all four renderers, RT_BENCH_FORCE_DIST=$FD (1 = a torch process group with RCCL up)"
+    RT_BENCH_FORCE_DIST=$FD python3 bench.py --steps 3 --warmup 1 --no-live-pmc --no-cpu-baseline --no-pipelined 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print({k:(v['value'],v['ms_per_step'],v['roofline'].get('stream_lanes') or v['roofline'].get('pipeline',{}).get('stream_lanes')) for k,v in d['renderers'].items()})"
+  done > $out/stream_pool.txt 2>&1
+  echo misc done ;;
+esac; done

@@ -6,7 +6,7 @@ import os
 import sys
 from pathlib import Path
 
-REPO = Path(__file__).resolve().parent.parent.parent
+REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "sycl-ray-tracer_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from rtamd import scenes

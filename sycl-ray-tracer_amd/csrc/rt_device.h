@@ -37,7 +37,7 @@ RT_DEV f3 cross3(f3 a, f3 b) {
 //     y = v_rcp_f32(x);  y + y * (1 - x * y)                                          (two fma)
 // IS RN(1 / x) for EVERY x whose biased exponent lies in 1..252, either sign, and
 //     r = v_rsq_f32(x);  g = x r, h = r / 2;  e = 1/2 - h g;  g += g e, h += h e;  g + h * (x - g g)        (Goldschmidt + one residual)
-// IS RN(sqrt(x)) for every x with biased exponent 25..254 — checked on ALL 2^32 inputs (scripts/fast_math_verify.hip chose the forms;
+// IS RN(sqrt(x)) for every x with biased exponent 25..254 — checked on ALL 2^32 inputs (a search over candidate forms in round 3 chose these;
 // rt_probe_rounding runs the check on the functions below, in the GPU test suite: tests/test_gpu_parity.py). Outside those ranges
 // (zero, denormals, huge, inf, NaN, negative radicands) a wave-uniform branch takes the compiler's IEEE sequence, so the functions
 // equal the IEEE expressions everywhere; inside, a normalisation costs 14 instructions instead of 28 + 11.

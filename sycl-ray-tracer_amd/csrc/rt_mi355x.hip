@@ -221,7 +221,7 @@ struct rt_renderer {
     std::chrono::high_resolution_clock::time_point pending_t0{};
     bool profile_kernels = false;
     std::vector<hipEvent_t> ev_pool;
-    // diagnostics (scripts/occupancy_probe.py): RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
+    // diagnostics: RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
     // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
     uint32_t hw_queues = 4; // GPU_MAX_HW_QUEUES as the host had set it when the renderer was created (4 = HIP's default): bounds the automatic stream lanes
     uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
