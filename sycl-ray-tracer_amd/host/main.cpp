@@ -33,7 +33,9 @@ static void usage(const char* argv0) {
                 "  --rr UINT                   Russian roulette from this bounce on (default 0 = off, as the reference)\n"
                 "  --schedule NAME             wavefront schedule: default (one launch per frame), per-sample, per-bounce (a launch pair per\n"
                 "                              bounce with compaction in between, the reference's), per-bounce-fused (one kernel per bounce)\n"
-                "  --quiet                     No loader chatter\n",
+                "  --quiet                     No loader chatter\n"
+                "\nThe camera must lie within 100 scene scales of the scene's bounds (scale = largest extent or coordinate): farther out the\n"
+                "conservative box culling of the closest-hit query no longer holds and the frame is refused with an error, not rendered wrong.\n",
                 argv0);
 }
 

@@ -93,6 +93,7 @@ def test_bench_launches_its_own_ranks(tmp_path, oracle, world):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == lines, "stdout carries the JSON line and nothing else:\n" + p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and d["steps"] == 3 and d["warmup"] == 1
     assert len(d["per_rank_ms"]) == world and all(ms > 0 for ms in d["per_rank_ms"]) and d["gather_ms"] > 0
