@@ -193,6 +193,10 @@ struct rt_renderer {
     //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
     //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
     rt_schedule sched{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u};
+    // waves per SIMD one k_wf_extend launch asks for; 0 = all 8 on one stream lane, 4 (one 1024-thread workgroup per CU) where lanes overlap: the
+    // lanes' launches then sit side by side instead of queueing workgroups behind each other (3 lanes: 190.4 -> 186.7 ms per frame, 2 lanes 205.0 ->
+    // 199.0; 2 / 6 waves: 201.6 / 190.8). RT_WF_EXTEND_OCC, tuning
+    uint32_t wf_extend_occ = 0;
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = kMegaWaves / stream lanes (RT_WF_FINISH_OCC, tuning)
     // SHOOT's input claims (round 3). A device atomic on the queue cursor serialises (~6 ns each, more under contention): with 128-slot
     // claims a 2 M-ray launch made 16 k of them, and smaller claims were far worse (64 slots: 4.7 -> 3.8 Grays/s, 32: 2.3). Now 85 % of
@@ -515,7 +519,7 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         grid[k] = (L.n_local + 255u) / 256u;
         // persistent EXTEND waves: fill every SIMD at the kernel's occupancy, never more than there are chunks
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
-                                                                            (uint32_t)r->n_cus * 4u * kExtendWaves));
+                                                                            (uint32_t)r->n_cus * 4u * (r->wf_extend_occ ? r->wf_extend_occ : (K >= 2 ? kExtendWaves / 2 : kExtendWaves))));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
         HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L)));
         HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L)));
@@ -1125,6 +1129,7 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
         if (const char* e = std::getenv("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
         if ((std::getenv("RT_WF_REQUEUE") || std::getenv("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
         if (const char* e = std::getenv("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
+        if (const char* e = std::getenv("RT_WF_EXTEND_OCC")) r->wf_extend_occ = (uint32_t)std::max(1, std::min((int)kExtendWaves, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
         if (const char* e = std::getenv("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
