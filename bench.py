@@ -67,9 +67,9 @@ SHOOT_BYTES_PER_RAY = 76
 #   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
 FINISH_BYTES_PER_PATH = 74
 MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel per frame (the timed region stores no RGBA8 image)
-# SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 48-B triangle records, 124 B of hit shading;
-# per-ray counts of the atrium measured with RT_KERNEL_STATS=1: 17.10 nodes, 4.60 triangles
-TRAVERSAL_BYTES_PER_RAY = 17.10 * 64 + 4.60 * 48 + 124
+# SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 40-B triangle records, 124 B of hit shading;
+# per-ray counts of the atrium measured with RT_KERNEL_STATS=1 (profiles/r04_wave_stats.txt): 17.28 nodes, 2.36 triangles
+TRAVERSAL_BYTES_PER_RAY = 17.28 * 64 + 2.36 * 40 + 124
 N_SIMDS = 1024                   # 256 CUs x 4
 RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce", "wavefront_per_bounce_fused")
 
