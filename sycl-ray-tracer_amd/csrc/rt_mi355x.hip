@@ -20,7 +20,6 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
-#include "rt_kernel_stream.h"
 #include "scene_build.h"
 
 using namespace rt;
@@ -171,14 +170,6 @@ struct rt_renderer {
         std::vector<unsigned long long> h_extra;
         hipStream_t stream = nullptr; // from the device's lane-stream pool (lane_stream_of) unless stream_owned
         bool stream_owned = false;
-        // the overlapped per-bounce schedule (rt_kernel_stream.h, fused_bounce = 2): three rotating queues with validity words, the control
-        // words of every (sample, bounce) — count, cursor, two done words — the second stream (pool stream 1), an event per stream
-        QueueDev wsq[3]{};
-        unsigned long long* ws_v[3] = {nullptr, nullptr, nullptr};
-        uint32_t* d_ws_ctl = nullptr;
-        uint32_t ws_cap = 0; // slots of each of the three queues
-        hipStream_t stream2 = nullptr;
-        hipEvent_t ev_ws[2] = {nullptr, nullptr};
         hipEvent_t ev_done = nullptr;
         std::vector<hipEvent_t> ev_pool;
         size_t n_hot = 0;
@@ -205,7 +196,6 @@ struct rt_renderer {
     // waves per SIMD one k_wf_extend launch asks for; 0 = all 8 on one stream lane, 4 (one 1024-thread workgroup per CU) where lanes overlap: the
     // lanes' launches then sit side by side instead of queueing workgroups behind each other (3 lanes: 190.4 -> 186.7 ms per frame, 2 lanes 205.0 ->
     // 199.0; 2 / 6 waves: 201.6 / 190.8). RT_WF_EXTEND_OCC, tuning
-    uint32_t ws_tag = 0; // the overlapped schedule: every launch's queue entries carry its tag (never 0, never repeated in 2^32 launches)
     uint32_t wf_extend_occ = 0;
     uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = kMegaWaves / stream lanes (RT_WF_FINISH_OCC, tuning)
     // SHOOT's input claims (round 3). A device atomic on the queue cursor serialises (~6 ns each, more under contention): with 128-slot
@@ -258,11 +248,6 @@ void free_tile_buffers(rt_renderer* r) {
     for (auto& L : r->lanes) {
         fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra), fr(L.d_cost), fr(L.d_tile_key), fr(L.d_tile_order);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
-        for (auto& q : L.wsq) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
-        for (auto& v : L.ws_v) fr(v);
-        fr(L.d_ws_ctl);
-        for (auto& e : L.ev_ws)
-            if (e) (void)hipEventDestroy(e), e = nullptr;
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.stream && L.stream_owned) (void)hipStreamDestroy(L.stream);
@@ -318,9 +303,6 @@ bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch ==
 // process environment (round 3 set the variable from a constructor: a side effect of dlopen, and void when HIP was already up). It READS what the
 // host configured when a renderer is created, and resolves an automatic lane count down to what the queues can serve: lanes + 2 <= queues. The
 // host (bench.py, the raytracer CLI) sets GPU_MAX_HW_QUEUES=8 itself before HIP starts; rt_stats reports both numbers.
-// the overlapped per-bounce schedule: every bounce a launch, consecutive launches on two streams (one lane: its two launches fill the machine)
-constexpr uint32_t kWsCtlWords = 96; // control words per (sample, bounce): three 128-byte lines
-bool wf_overlapped(const rt_renderer* r) { return r->sched.fused_bounce == 2u && r->sched.finish_depth >= r->max_depth && r->max_depth > 0; }
 uint32_t hw_queues_from_env() {
     const char* e = std::getenv("GPU_MAX_HW_QUEUES");
     const int v = e ? std::atoi(e) : 0;
@@ -328,7 +310,7 @@ uint32_t hw_queues_from_env() {
 }
 uint32_t wf_stream_lanes(const rt_renderer* r) {
     if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u); // explicit: the caller's business
-    if (wf_one_launch(r) || wf_overlapped(r)) return 1u;
+    if (wf_one_launch(r)) return 1u;
     uint32_t want = r->sched.fused_bounce || r->sched.finish_depth >= r->max_depth ? 3u : 2u;
     while (want > 2u && want + 2u > r->hw_queues) want--;
     return want;
@@ -444,24 +426,7 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
             const size_t m = std::max<size_t>(L.n_local, 1);
             // SHOOT launches reserve the next queue in blocks of kOutBlock slots per workgroup: up to one partly used block per workgroup
             const size_t mq = m + (per_bounce && r->sched.fused_bounce ? (size_t)kOutBlock * ((size_t)r->n_cus * 4u * kMegaWaves / (kMegaBlock / 64) + 1u) : 0u);
-            if (wf_overlapped(r)) { // three rotating queues (a launch reads one while its producer still fills it and writes the next), widened u16 plane
-                for (int qi = 0; qi < 3; ++qi) {
-                    auto& q = L.wsq[qi];
-                    HIPCHK(dalloc((void**)&q.org_id, mq * 16));
-                    HIPCHK(dalloc((void**)&q.a, mq * 8));
-                    HIPCHK(dalloc((void**)&q.b, mq * 8));
-                    HIPCHK(dalloc((void**)&q.c, mq * 4));
-                    HIPCHK(dalloc((void**)&L.ws_v[qi], mq * 8));
-                    HIPCHK(hipMemsetAsync(L.ws_v[qi], 0, mq * 8, r->stream)); // tag 0 is never a launch's
-                }
-                L.ws_cap = (uint32_t)mq;
-                HIPCHK(dalloc((void**)&L.d_ws_ctl, (size_t)r->spp * ((size_t)r->max_depth + 1u) * kWsCtlWords * 4u));
-                HIPCHK(hipStreamSynchronize(r->stream));
-                bool owned2 = false;
-                HIPCHK(lane_stream_of(r->scene->device, 1, &L.stream2, &owned2));
-                for (auto& e : L.ev_ws) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-            for (int qi = 0; qi < (wf_overlapped(r) ? 0 : per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
+            for (int qi = 0; qi < (per_bounce ? 2 : 1); ++qi) { // k_wf_generate -> k_wf_finish needs one queue and no hit records
                 auto& q = L.q[qi];
                 HIPCHK(dalloc((void**)&q.org_id, mq * 16));
                 HIPCHK(dalloc((void**)&q.a, mq * 8));
@@ -571,63 +536,6 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
     // cost ordering (one-launch schedule, one stream lane): sample 0 in a launch of its own, then all the others, most expensive blocks first
     const bool lpt = K == 1 && r->lanes[0].n_tiles != 0 && chunk == r->spp && D0 == 0 && D > 0;
     const bool shoot_frame = r->sched.fused_bounce && D0 > 0; // queues may hold holes: every launch counts its rays on the device
-    if (wf_overlapped(r) && K == 1 && r->lanes[0].n_local) {
-        // Every bounce a launch of k_ws_shoot; bounce d on stream d & 1, so that the launch of bounce d + 1 runs while bounce d still fills its
-        // queue (at most two resident, each asking for half of the wave slots). A sample's camera rays need the RNG words its previous sample's
-        // paths left behind: k_ws_generate waits for both streams.
-        auto& L = r->lanes[0];
-        hipStream_t ss[2] = {L.stream, L.stream2};
-        if (const char* e = std::getenv("RT_WS_SERIAL")) { if (e[0] == '1') ss[1] = ss[0]; } // experiment: no overlap (every launch behind its producer)
-        HIPCHK(hipMemsetAsync(L.d_ws_ctl, 0, (size_t)r->spp * ((size_t)D + 1u) * kWsCtlWords * 4u, st)); // every (sample, bounce)'s count, cursor and done words
-        HIPCHK(hipEventRecord(r->ev_fork, st)); // behind the frame's set-up on `st` (camera copy, k_wf_init, the counters' memsets)
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ss[i], r->ev_fork, 0));
-        constexpr uint32_t wpb = kMegaBlock / 64;
-        const uint32_t cap = (uint32_t)r->n_cus * 4u * (r->wf_finish_occ ? r->wf_finish_occ : kMegaWaves / 2u);
-        const uint32_t waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + 63u) / 64u, cap));
-        const uint32_t sgrid = (waves + wpb - 1u) / wpb;
-        uint32_t* err = reinterpret_cast<uint32_t*>(L.d_extra + r->spp);
-        auto ctl = [&](uint32_t s, uint32_t d, int what) { // 0 count, 1 cursor, 2 done[2]: a 128-byte line each (producers' atomics, consumers' atomics and
-            uint32_t* base = L.d_ws_ctl + ((size_t)s * (D + 1u) + d) * kWsCtlWords; // everybody's polls would otherwise meet in one cache line)
-            return base + 32u * (uint32_t)what;
-        };
-        for (uint32_t s = 0; s < r->spp; ++s) {
-            // (the first launch of a sample on stream 0 waits for the previous sample's launches on stream 1, and the other way round)
-            if (s) {
-                HIPCHK(hipStreamWaitEvent(ss[0], L.ev_ws[1], 0));
-                HIPCHK(hipStreamWaitEvent(ss[1], L.ev_ws[0], 0));
-            }
-            uint32_t tag_in = ++r->ws_tag;
-            if (tag_in == 0u) tag_in = ++r->ws_tag;
-            StreamQueue qin{L.wsq[0], L.ws_v[0], ctl(s, 0, 0), ctl(s, 0, 2), tag_in, L.ws_cap};
-            hipLaunchKernelGGL(k_ws_generate, dim3(grid[0]), dim3(256), 0, ss[0], r->d_cam, L.tile, L.n_local, L.d_rng, qin);
-            launches.add(RT_K_WF_GENERATE);
-            for (uint32_t d = 0; d < D; ++d) {
-                uint32_t tag_out = ++r->ws_tag;
-                if (tag_out == 0u) tag_out = ++r->ws_tag;
-                StreamQueue qout{L.wsq[(d + 1u) % 3u], L.ws_v[(d + 1u) % 3u], ctl(s, d + 1u, 0), ctl(s, d + 1u, 2), tag_out, L.ws_cap};
-                if (r->d_stats)
-                    hipLaunchKernelGGL(k_ws_shoot<true>, dim3(sgrid), dim3(kMegaBlock), 0, ss[d & 1u], S, L.tile, qin, qout, ctl(s, d, 1), L.d_rng, L.d_accum, L.d_extra + s, d, D,
-                                       r->rr_start, err, r->d_stats);
-                else
-                    hipLaunchKernelGGL(k_ws_shoot<false>, dim3(sgrid), dim3(kMegaBlock), 0, ss[d & 1u], S, L.tile, qin, qout, ctl(s, d, 1), L.d_rng, L.d_accum, L.d_extra + s, d, D,
-                                       r->rr_start, err, (unsigned long long*)nullptr);
-                launches.add(RT_K_WF_SHOOT);
-                qin = qout;
-            }
-            HIPCHK(hipEventRecord(L.ev_ws[0], ss[0]));
-            HIPCHK(hipEventRecord(L.ev_ws[1], ss[1]));
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamWaitEvent(ss[0], L.ev_ws[1], 0));
-        hipLaunchKernelGGL(k_wf_resolve, dim3(grid[0]), dim3(256), 0, ss[0], L.n_local, r->spp, (uint32_t)r->width, r->tile.strip_rows, 1u, 0u, L.d_accum, d_f32, d_u8);
-        launches.add(RT_K_WF_RESOLVE);
-        HIPCHK(hipEventRecord(L.ev_done, ss[0]));
-        HIPCHK(hipStreamWaitEvent(st, L.ev_done, 0));
-        HIPCHK(hipGetLastError());
-        *n_hot_events = 0;
-        *launches_out = launches;
-        return RT_OK;
-    }
     for (uint32_t s = 0; s < r->spp;) {
         const uint32_t n_samples = lpt ? (s == 0 ? 1u : r->spp - 1u) : std::min(chunk, r->spp - s);
         const bool ordered = lpt && s > 0;
@@ -1296,7 +1204,7 @@ int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out) {
 int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
     if (!r || !s) return fail(RT_ERR_INVALID, "null argument");
     if (s->stream_lanes > 8) return fail(RT_ERR_INVALID, "at most 8 stream lanes");
-    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1 || s->fused_bounce > 2)
+    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1 || s->fused_bounce > 1)
         return fail(RT_ERR_INVALID, "schedule field out of range");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     if (r->kind != RT_RENDERER_WAVEFRONT) return RT_OK; // the megakernel is one launch: nothing to schedule

@@ -152,7 +152,7 @@ class IRenderer:
         reference has one: a launch per bounce, src/render_wavefront.cpp:396-417 = finish_depth=abi.RT_SCHED_ALL_BOUNCES).
         Frame.kernels reports what ran. The megakernel ignores it."""
         sc = abi.rt_schedule(int(finish_depth), int(samples_per_launch), int(stream_lanes), int(requeue), int(bool(reorder)),
-                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(fused_bounce))
+                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(bool(fused_bounce)))
         abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)))
 
     def get_schedule(self) -> abi.rt_schedule:
