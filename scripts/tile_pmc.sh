@@ -14,7 +14,8 @@ for WORLD in $WORLDS; do
            "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" \
            "SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD"; do
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_GATE_EN1_sum"; do
     i=$((i+1))
     timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/w${WORLD}_p$i -- python3 scripts/tile_scaling.py 64 $R $WORLD > $O/w${WORLD}_p$i.out 2> $O/w${WORLD}_p$i.err || { echo "pass $i (1/$WORLD) failed"; tail -3 $O/w${WORLD}_p$i.err; }
   done
@@ -56,6 +57,13 @@ for w in worlds:
               % (c.get("TCP_TCP_LATENCY_sum", 0) / max(c.get("TCP_TCC_READ_REQ_sum", 0), 1), c.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / max(c.get("TCP_TCC_READ_REQ_sum", 0), 1),
                  c.get("TCP_PENDING_STALL_CYCLES_sum", 0) / 256 / cyc if cyc else 0, c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0), 1),
                  c.get("SQ_INST_LEVEL_VMEM", 0) / max(c.get("SQ_WAVE_CYCLES", 0), 1)))
+        # the vector L1 looks one cache line up per cycle and CU: a lane's 16-byte load is one access, four of them fetch a node
+        l1 = c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0)
+        if l1:
+            rays = {"8": 135898371, "4": 272335626, "2": 545124372, "1": 1082550484}.get(w, 0) * len(n_launch[k])  # (the bench frame's tiles, megakernel seeds)
+            print("   vector L1: %.3f tag look-ups per cycle and CU (1 = its rate), %.1f per ray | read tag-conflict stalls %.3f, address stalls towards the TA %.3f of the cycles"
+                  % (l1 / 256 / cyc if cyc else 0, l1 / rays if rays else 0, c.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0) / 256 / cyc if cyc else 0,
+                     c.get("TCP_TCP_TA_ADDR_STALL_CYCLES_sum", 0) / 256 / cyc if cyc else 0))
         wc = c.get("SQ_WAVE_CYCLES", 0)
         print("   per wave-cycle: waiting (any) %.3f, issuing (any) %.3f | SQ_BUSY_CYCLES %.4g | LDS wait %.3g active %.3g | VMEM active %.3g"
               % (c.get("SQ_WAIT_INST_ANY", 0) / wc if wc else 0, c.get("SQ_ACTIVE_INST_ANY", 0) / wc if wc else 0, c.get("SQ_BUSY_CYCLES", 0),
