@@ -280,7 +280,7 @@ RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
     }
 }
 
-// The first kTopNodes nodes of the breadth-first node array (the top ~5 levels of the BVH4) are staged in
+// The first kTopNodes nodes of the node array (the top of the BVH4: scene_build.cpp orders them by surface area, ~5 levels) are staged in
 // LDS by every workgroup of the traversal kernels, as four structure-of-arrays planes of 16 bytes per node (the node's
 // four 16-byte words), so that the 16-byte reads of different nodes spread over the banks. Measured on the atrium: 9.5 of the 17.9 inner-node
 // visits of an average ray fall into these nodes; taking them out of the vector L1 path (the first
@@ -435,19 +435,17 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;
     const uint32_t first = code >> 2, rem = code & 3u;
     if (BATCH) {
+        static_assert(kMaxLeafTris == 2 && kTriBytes == 40, "the whole-leaf step reads a leaf as 80 contiguous bytes");
+        // The two records of a leaf are 80 contiguous bytes: FIVE 16-byte loads instead of 2 x (16 + 16 + 8) — one look-up less in the vector
+        // L1 per leaf, the path this kernel loads most. A leaf of one record reads 8 bytes of the next record with its third
+        // load (the buffer ends in 16 bytes of padding, rt_mi355x.hip: rt_scene_create).
         const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
-        float4 a = tri_ld4(p4), b = tri_ld4(p4 + 16);
-        float2 c = tri_ld2(p4 + 32);
-        uint32_t k = 1;
-        for (; k < (uint32_t)kMaxLeafTris; ++k) {
-            if (__ballot(k <= rem) == 0ull) break;
-            float4 na = a, nb = b;
-            float2 nc = c;
-            if (k <= rem) na = tri_ld4(p4 + k * kTriBytes), nb = tri_ld4(p4 + k * kTriBytes + 16), nc = tri_ld2(p4 + k * kTriBytes + 32);
-            if (k - 1u <= rem) tri_test_regs(a, b, c, T.o, T.d, T.best);
-            a = na, b = nb, c = nc;
+        const float4 l0 = tri_ld4(p4), l1 = tri_ld4(p4 + 16), l2 = tri_ld4(p4 + 32), l3 = tri_ld4(p4 + 48), l4 = tri_ld4(p4 + 64);
+        const bool two = rem != 0u;
+        tri_test_regs(l0, l1, make_float2(l2.x, l2.y), T.o, T.d, T.best);
+        if (__ballot(two) != 0ull) {
+            if (two) tri_test_regs(make_float4(l2.z, l2.w, l3.x, l3.y), make_float4(l3.z, l3.w, l4.x, l4.y), make_float2(l4.z, l4.w), T.o, T.d, T.best);
         }
-        if (rem + 1u >= k) tri_test_regs(a, b, c, T.o, T.d, T.best); // triangle k-1, still untested where it exists
         if (lanes(!stack_shallow(stack, T, 0u)) == 0ull) trav_pop_lds(T, stack);
         else trav_pop(T, stack);
     } else {

@@ -991,7 +991,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
             rc = upload(dn, &s->dev.nodes, s->device_bytes);
         }
         if (rc == RT_OK) { // the device's triangle records: the host records' ten live dwords at a kTriBytes stride
-            std::vector<uint8_t> packed(s->hs.tris.size() * (size_t)kTriBytes + 16, 0); // + 16: a 16-byte load at the last record's offset 32 stays inside
+            std::vector<uint8_t> packed(s->hs.tris.size() * (size_t)kTriBytes + 48, 0); // + 48: the whole-leaf step reads 80 bytes at every leaf, also at a last leaf of one record
             for (size_t i = 0; i < s->hs.tris.size(); ++i) std::memcpy(packed.data() + i * kTriBytes, &s->hs.tris[i], std::min<size_t>(kTriBytes, sizeof(TriRec)));
             rc = upload(packed, &s->dev.tris, s->device_bytes);
         }

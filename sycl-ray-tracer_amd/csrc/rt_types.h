@@ -35,7 +35,7 @@ constexpr int32_t kChildEmpty = (int32_t)0x80000000;
 // addresses the node with no arithmetic of its own — a 32-bit offset on the scalar base for global memory (the index form cost a
 // 64-bit shift and a 64-bit add per step), one right shift for the LDS copy of the tree's top. The host array keeps indices.
 constexpr int kMaxLeafTris = 2;    // 1..4 (the leaf code keeps count - 1 in two bits). 4 -> 2: +1.1 % on the atrium — a whole-leaf step runs as many tests as the wave's LARGEST leaf
-constexpr int kTopNodes = 341;    // nodes at the head of the node array laid out breadth first (scene_build.cpp) and staged in LDS by the traversal kernels (rt_device.h)
+constexpr int kTopNodes = 341;    // nodes at the head of the node array laid out top first — by surface area: scene_build.cpp; by level: lbvh_gpu.hip — and staged in LDS by the traversal kernels (rt_device.h)
 constexpr int kStackSize = 64;      // traversal stack entries per ray; builders keep depth < 64
 constexpr uint32_t kNoTri = 0xFFFFFFFFu;
 constexpr float kTNear = 0.0001f;   // RayData::to_embree tnear (src/camera.hpp:50)

