@@ -241,28 +241,23 @@ RT_DEV void trav_begin(Trav& T, f3 o, f3 d, const TravStack& st) {
 // v_sub_u32 + ds_read, with no index -> address arithmetic (v_lshl_or_b32 is a 4-cycle instruction) and no per-push depth test:
 // a step asks ONCE, wave-uniformly, whether every lane's next three pushes and its pop stay inside the LDS part (they nearly
 // always do) and only otherwise takes the general routines, which turn the address back into an entry index.
+// (Round 4) Nothing on the common path branches: entry 0 of every lane's stack is a sentinel that holds kTravDone, so a pop needs no
+// test for an empty stack, and an inner step WRITES its three candidate words to the next free entries in any case — only the stack
+// pointer depends on the hits (trav_inner). Each removed exec-mask save / branch / restore was worth ~1 % of the frame.
 constexpr int kLdsStack = 12;
 typedef __attribute__((address_space(3))) int32_t lds_i32; // forces ds_read/ds_write (never flat_*)
 struct TravStack {
-    uint32_t base;  // LDS byte address of this lane's entry 0
+    uint32_t base;  // LDS byte address of this lane's entry 0 (the sentinel)
     int32_t* spill; // kStackSize - kLdsStack entries of scratch
     uint32_t pitch; // bytes from one entry of a lane to its next: 4 * threads per block (a power of two)
 };
-RT_DEV uint32_t stack_base(const TravStack& st) { return st.base; }
+RT_DEV uint32_t stack_base(const TravStack& st) { return st.base + st.pitch; } // the first entry above the sentinel
 RT_DEV lds_i32* lds_at(uint32_t addr) { return (lds_i32*)(size_t)addr; }
 // true when the lane's next `pushes` pushes and a pop all stay inside the LDS part of its stack
 RT_DEV bool stack_shallow(const TravStack& st, const Trav& T, uint32_t pushes) { return T.sp <= st.base + ((uint32_t)kLdsStack - pushes) * st.pitch; }
-RT_DEV void stk_push_lds(const TravStack& st, Trav& T, int32_t v) { // caller: stack_shallow
-    *lds_at(T.sp) = v;
-    T.sp += st.pitch;
-}
 RT_DEV void trav_pop_lds(Trav& T, const TravStack& st) { // caller: stack_shallow
-    if (T.sp != st.base) {
-        T.sp -= st.pitch;
-        T.cur = *lds_at(T.sp);
-    } else {
-        T.cur = kTravDone;
-    }
+    T.sp -= st.pitch; // entry 0 holds kTravDone (RT_TRAVERSAL_LDS): popping an empty stack ends the traversal with no test of its own
+    T.cur = *lds_at(T.sp);
 }
 RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) { // any depth
     const uint32_t e = (T.sp - st.base) / st.pitch;
@@ -271,13 +266,9 @@ RT_DEV void stk_push(const TravStack& st, Trav& T, int32_t v) { // any depth
     T.sp += st.pitch;
 }
 RT_DEV void trav_pop(Trav& T, const TravStack& st) { // any depth
-    if (T.sp != st.base) {
-        T.sp -= st.pitch;
-        const uint32_t e = (T.sp - st.base) / st.pitch;
-        T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
-    } else {
-        T.cur = kTravDone;
-    }
+    T.sp -= st.pitch;
+    const uint32_t e = (T.sp - st.base) / st.pitch;
+    T.cur = e < (uint32_t)kLdsStack ? *lds_at(T.sp) : st.spill[e - (uint32_t)kLdsStack];
 }
 
 // The first kTopNodes nodes of the node array (the top of the BVH4: scene_build.cpp orders them by surface area, ~5 levels) are staged in
@@ -360,9 +351,20 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         w0 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w0 + o), w1 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w1 + o);
         w2 = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.w2 + o), chw = *(lds_u32x4*)(size_t)((uint32_t)(size_t)top.ch + o);
     } else {
-        const u32x4* np = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)T.cur);
-        w0 = np[0], w1 = np[1], w2 = np[2], chw = np[3];
+        // The four 16-byte words of a node in global memory, issued from inline assembly so that hipcc's wait-count pass does not see them:
+        // it would otherwise hold the LDS reads of the other lanes back until these loads have RETURNED (s_waitcnt vmcnt(0) in front of the
+        // ds_read_b128s — both write the same registers, and the pass does not reason about disjoint exec masks), which adds the LDS
+        // latency to the global one in every step that has lanes of both kinds. The hardware writes only the lanes each instruction was
+        // issued for. The wait these loads need is the explicit one below the join.
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                     "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+                     "global_load_dwordx4 %3, %4, %5 offset:48"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(chw)
+                     : "v"((uint32_t)T.cur), "s"(S.nodes)
+                     : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(chw));
     const float ax = __uint_as_float(w0.w) * T.ix;
     const float ay = __uint_as_float(w2.z) * T.iy;
     const float az = __uint_as_float(w2.w) * T.iz;
@@ -411,9 +413,14 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 #undef RT_CE
     const bool descend = k0 < inf;
     if (lanes(!stack_shallow(stack, T, 3u)) == 0ull) { // every lane of this step: LDS only (one wave-uniform test, no per-push ones)
-        if (k3 < inf) stk_push_lds(stack, T, c3); // farthest first (exactly so with the full network)
-        if (k2 < inf) stk_push_lds(stack, T, c2);
-        if (k1 < inf) stk_push_lds(stack, T, c1);
+        // pushes without branches: the word is written to the next free entry in any case (there is room for three, asked above), and
+        // only the stack pointer depends on the hit (three conditional pushes: three exec-mask regions with a branch each, -0.9 %)
+        *lds_at(T.sp) = c3; // farthest first (exactly so with the full network)
+        T.sp = sel(lanes(k3 < inf), T.sp, T.sp + stack.pitch);
+        *lds_at(T.sp) = c2;
+        T.sp = sel(lanes(k2 < inf), T.sp, T.sp + stack.pitch);
+        *lds_at(T.sp) = c1;
+        T.sp = sel(lanes(k1 < inf), T.sp, T.sp + stack.pitch);
         if (descend) T.cur = c0;
         else trav_pop_lds(T, stack);
     } else {

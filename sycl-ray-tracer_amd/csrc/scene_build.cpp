@@ -715,7 +715,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         }
         if (rc != RT_OK) return rc;
         hs.stack_need = need(0);
-        if (hs.stack_need + 1 >= (uint32_t)kStackSize) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err);
+        if (hs.stack_need + 2 >= (uint32_t)kStackSize) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err);
         // surface-area cost of the downloaded tree (the diagnostic rt_scene_info reports for the host builders too): every node's
         // children boxes decoded, inner child 1 step x area, leaf child (triangles) x area, relative to the root's area
         {
@@ -929,7 +929,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     }
     if (hs.tris.size() < T || hs.tris.size() > b.order.size()) { err = "internal: leaf record count mismatch after build"; return RT_ERR_INVALID; }
     hs.stack_need = need(0);
-    if (hs.stack_need + 1 >= (uint32_t)kStackSize) {
+    if (hs.stack_need + 2 >= (uint32_t)kStackSize) {
         if (bvh_kind != RT_BVH_MEDIAN_INTERNAL) return build_host_scene(d, RT_BVH_MEDIAN_INTERNAL, hs, err); // balanced fallback
         err = "internal: BVH deeper than the traversal stack";
         return RT_ERR_INVALID;
