@@ -355,7 +355,7 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         // it would otherwise hold the LDS reads of the other lanes back until these loads have RETURNED (s_waitcnt vmcnt(0) in front of the
         // ds_read_b128s — both write the same registers, and the pass does not reason about disjoint exec masks), which adds the LDS
         // latency to the global one in every step that has lanes of both kinds. The hardware writes only the lanes each instruction was
-        // issued for. The wait these loads need is the explicit one below the join.
+        // issued for. The waits these loads need are the two explicit ones below the join (loads return in order: three words, then the fourth).
         asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
                      "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
@@ -364,7 +364,7 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
                      : "v"((uint32_t)T.cur), "s"(S.nodes)
                      : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(chw));
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(w0), "+v"(w1), "+v"(w2)); // the child words (the fourth load) are not needed before the sort
     const float ax = __uint_as_float(w0.w) * T.ix;
     const float ay = __uint_as_float(w2.z) * T.iy;
     const float az = __uint_as_float(w2.w) * T.iz;
@@ -383,7 +383,6 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
     // of origin * inv - o * inv on all three axes at once (entry == exit), and out there the padded boxes are no longer conservative
     // for any child, absent or not — so the child words are not tested here (an explicit kChildEmpty test per slot was measured at
     // 12 issue cycles of ~500 per step).
-    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
 #define RT_CHILD(K, CVT)                                                                                  \
     {                                                                                                    \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(CVT(qnx), ax, bx), __builtin_fmaf(CVT(qny), ay, by)), \
@@ -406,6 +405,8 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
         const int32_t ca = sel(sw, CA, CB), cb = sel(sw, CB, CA);                   \
         KA = ka, KB = kb, CA = ca, CB = cb;                                         \
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(chw));
+    int32_t c0 = (int32_t)chw.x, c1 = (int32_t)chw.y, c2 = (int32_t)chw.z, c3 = (int32_t)chw.w;
     RT_CE(k0, c0, k1, c1)
     RT_CE(k2, c2, k3, c3)
     RT_CE(k0, c0, k2, c2)
