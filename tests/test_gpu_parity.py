@@ -1229,3 +1229,50 @@ def test_frames_of_two_renderers_in_flight_at_once(oracle, scene_cache, cls, kin
     with pytest.raises(RuntimeError, match="no frame in flight"):
         a.end_frame()
     a.close(), b.close(), gs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bvh", [abi.RT_BVH_SAH, abi.RT_BVH_LBVH, abi.RT_BVH_LBVH_GPU])
+def test_deep_traversal_stacks_spill_and_equal_the_oracle(oracle, bvh):
+    """A pile of 8,192 large parallel triangles with one bounding box. All but two of them leave the corner free through which the
+    rays pass, so a ray that looks down the pile enters EVERY child box of every node on its first descent and meets nothing: its stack
+    grows by up to three entries per level — past the 11 usable LDS entries into the scratch spill (rt_device.h: stk_push / trav_pop,
+    the sentinel in entry 0) — and the triangle it does hit (the sixth from either end) sits in a NEAR sibling, i.e. behind an entry that
+    went through the spill. Batch queries and renders against brute force."""
+    n = 8192
+    z = -np.arange(n, dtype=np.float32) / np.float32(n)
+    pos = np.zeros((n, 3, 3), np.float32)
+    pos[:, 0] = (5.0, -5.0, 0.0)   # the hypotenuse: the same for both kinds
+    pos[:, 1] = (-5.0, 7.0, 0.0)
+    pos[:, 2] = (-5.0, -5.0, 0.0)  # kind B: covers 12 x + 10 y < 10, NOT the rays' corner (x, y in 1.5 .. 3)
+    pos[[5, n - 6], 2] = (5.0, 7.0, 0.0)  # kind A: the other half of the same box
+    pos[:, :, 2] = z[:, None]
+    sb = scenes.SceneBuilder("pile")
+    mat = sb.add_material(scenes.Material(abi.RT_MAT_DIFFUSE, (0.7, 0.6, 0.5)))
+    p = pos.reshape(-1, 3)
+    nrm = np.tile(np.array([0.0, 0.0, 1.0], np.float32), (p.shape[0], 1))
+    uv = np.zeros((p.shape[0], 2), np.float32)
+    sb.add_instance(sb.add_mesh(p, nrm, uv, np.arange(p.shape[0], dtype=np.uint32).reshape(-1, 3)), mat, scenes.trs((0, 0, 0), (0, 0, 0, 1), (1, 1, 1)))
+    sd = sb.build()
+    sd.camera = scenes.CameraPose((2.25, 2.25, 3.0), (0.0, 0.0, -1.0), 6.0)  # a narrow view down the free corner
+    gs, osc = Scene(sd, 0, bvh), oracle.OracleScene(sd)
+    gs.check_bvh()
+    assert gs.info().max_depth >= 6  # 3 pushes per level on the first descent: more than the LDS part of the stack holds
+    rng = np.random.default_rng(11)
+    m = 4096
+    org = np.stack([rng.uniform(1.5, 3.0, m), rng.uniform(1.5, 3.0, m), rng.uniform(0.5, 3.0, m)], -1).astype(np.float32)
+    org[m // 2:, 2] = rng.uniform(-3.0, -1.5, m - m // 2).astype(np.float32)  # half of them from below the pile, looking up
+    dirs = np.stack([rng.normal(0, 0.02, m), rng.normal(0, 0.02, m), np.where(org[:, 2] > 0, -1.0, 1.0)], -1).astype(np.float16).astype(np.float32)
+    g, e = gs.intersect(org, dirs), osc.intersect(org, dirs, use_bvh=False)
+    for a, b in zip(g, e):
+        np.testing.assert_array_equal(a, b)
+    assert (e[3] != NO_TRI).sum() > m * 0.9 and set(np.unique(e[3][e[3] != NO_TRI])) == {5, n - 6}
+    w, h = 64, 48
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    for cls, kind in KINDS:
+        r = cls(gs, (w, h), 4, 2)
+        fr = r.render_frame(Camera.for_scene(sd, (w, h)))
+        f, b, rays = osc.render(ocam, kind, 4, 2, use_bvh=False)
+        _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, f, b, rays, f"pile {kind}")
+        r.close()
+    gs.close()
