@@ -434,10 +434,9 @@ RT_DEV void trav_inner(const SceneDev& S, Trav& T, const TravStack& stack, const
 }
 
 // leaf step. BATCH = false: ONE triangle of the leaf per step, then the next one or pop (rt_intersect_batch).
-// BATCH = true (both renderers): all 1..4 triangles in this step — a lane at a leaf waits for the leaf class to win
-// the wave's vote, so every extra leaf step costs it several iterations; the next record is fetched while the current
-// one is tested (two in flight, 24 VGPRs), the loop bound is the wave's largest leaf (uniform branch). Measured on the
-// megakernel: 12.5 M -> 6.2 M leaf steps per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2, once its registers allowed it).
+// BATCH = true (both renderers): the whole leaf (1-2 triangles) in this step — a lane at a leaf waits for the leaf class to win
+// the wave's vote, so every extra leaf step costs it several iterations. Measured on the megakernel: 12.5 M -> 6.2 M leaf steps
+// per 4-spp frame, +2.5 % rays/s; EXTEND: +6 % (round 2). Round 4: no loop and no masked loads any more (below): +4.8 %.
 template <bool BATCH>
 RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     const uint32_t code = (uint32_t)~T.cur;
@@ -445,8 +444,10 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
     if (BATCH) {
         static_assert(kMaxLeafTris == 2 && kTriBytes == 40, "the whole-leaf step reads a leaf as 80 contiguous bytes");
         // The two records of a leaf are 80 contiguous bytes: FIVE 16-byte loads instead of 2 x (16 + 16 + 8) — one look-up less in the vector
-        // L1 per leaf, the path this kernel loads most. A leaf of one record reads 8 bytes of the next record with its third
-        // load (the buffer ends in 16 bytes of padding, rt_mi355x.hip: rt_scene_create).
+        // L1 per leaf, the path this kernel loads most — and all five UNCONDITIONAL: a leaf of one record (2 % of the SAH
+        // leaves, every LBVH leaf) reads 40 bytes of its neighbour and ignores them (the buffer ends in 48 bytes of padding, rt_mi355x.hip:
+        // rt_scene_create). With the second record's loads under `if (two)` the first test waited for all five at the join and eight
+        // v_movs initialised the merged registers: 134.1 instead of 126.5 ms per frame (EXPERIMENTS.md).
         const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
         const float4 l0 = tri_ld4(p4), l1 = tri_ld4(p4 + 16), l2 = tri_ld4(p4 + 32), l3 = tri_ld4(p4 + 48), l4 = tri_ld4(p4 + 64);
         const bool two = rem != 0u;
