@@ -1276,3 +1276,26 @@ def test_deep_traversal_stacks_spill_and_equal_the_oracle(oracle, bvh):
         _assert_frames_equal(fr.rgba_f32, fr.rgba_u8, fr.rays, f, b, rays, f"pile {kind}")
         r.close()
     gs.close()
+
+
+@pytest.mark.gpu
+def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypatch, capfd):
+    """RT_KERNEL_STATS=1 selects the STATS instantiations of the traversal kernels (wave-level step counters, scripts/final_profile.sh
+    stats): separate kernels compiled from the same source, so they are held to the same frame — megakernel, the wavefront renderer's
+    one-launch schedule and its per-bounce pair — and must print their report."""
+    gs = gpu_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 96, 64, 6, 4
+    cam = Camera.for_scene(sd, (w, h))
+    monkeypatch.setenv("RT_KERNEL_STATS", "1")
+    for cls, kind, sched in [(MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL, None), (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, None),
+                             (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(finish_depth=ALL_BOUNCES, fused_bounce=0)),
+                             (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(finish_depth=ALL_BOUNCES, fused_bounce=1))]:
+        f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp)
+        r = cls(gs, (w, h), depth, spp)
+        if sched:
+            r.set_schedule(**sched)
+        got = r.render_frame(cam)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"stats {cls.__name__} {sched}")
+        r.close()
+    assert "[rt stats]" in capfd.readouterr().err
