@@ -44,7 +44,7 @@ RT_DEV f3 cross3(f3 a, f3 b) {
 RT_DEV float rcp_rn(float x) { // == 1.0f / x
     const uint32_t t = __float_as_uint(x) + __float_as_uint(x); // the sign shifted out
     const bool ok = t - 0x01000000u < 0xFC000000u;              // biased exponent 1 .. 252
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) == 0ull, 1)) {
         const float y = __builtin_amdgcn_rcpf(x);
         return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
     }
@@ -52,7 +52,7 @@ RT_DEV float rcp_rn(float x) { // == 1.0f / x
 }
 RT_DEV float inv_sqrt2(float x) { // == 1.0f / sqrtf(x): two roundings, as glm::normalize / sycl::normalize
     const bool ok = __float_as_uint(x) - 0x0C800000u < 0x73000000u; // positive, biased exponent 25 .. 254
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) == 0ull, 1)) {
         const float r = __builtin_amdgcn_rsqf(x);
         float g = x * r, h = 0.5f * r;
         const float e = __builtin_fmaf(-h, g, 0.5f);
@@ -596,11 +596,41 @@ RT_DEV bool scatter(const SceneDev& S, const MatRec& m, uint32_t& rng, f3 dir, f
     return false; // eNone
 }
 
+// ---- the scene's commonest normal matrices and materials in LDS (round 5) ------------------------------------------------------
+// A shading round is a chain of dependent fetches — shading record -> material (+ instance) -> texel — run at the lower issue priority,
+// and 14 % of a wave's time. The middle link reads two tiny tables (the atrium: 5 distinct normal matrices, 12 materials) through the
+// vector memory path. Every workgroup of a kernel that shades stages the head of both tables in LDS (kLdsNm matrices, kLdsMats materials: 1,152 bytes): the material is
+// then an LDS read away from the shading word, the texel fetch leaves one memory round trip after the shading record's, and the normal
+// matrix is read where it is used instead of living in nine registers while the texel is in flight.
+//   nm  : 3 x 16 bytes per matrix, the device's InstRec as it is (m[0..3], m[4..7], m[8], -, -, -)
+//   mat : 2 x 16 bytes per material: {type | tex_kind << 8 | tex_layer << 16, colour rgb}, {emissive rgb, roughness (metallic) or ior (dielectric)}
+// A round whose hits all index inside the staged part takes the LDS path; any other (a scene with more than kLdsNm matrices in use or
+// more than kLdsMats materials, or without the packed shading word) takes the memory path — a wave-uniform choice per round.
+struct ShadeTables {
+    lds_u32x4* nm;
+    lds_u32x4* mat;
+    uint32_t n_nm, n_mat; // entries staged
+};
+RT_DEV void shade_tables_fill(const SceneDev& S, u32x4* nm, u32x4* mat) { // cooperative; the caller synchronises afterwards
+    const u32x4* in = reinterpret_cast<const u32x4*>(S.inst);
+    for (uint32_t i = threadIdx.x; i < S.lds_nm * 3u; i += blockDim.x) nm[i] = in[i];
+    for (uint32_t i = threadIdx.x; i < S.lds_mats; i += blockDim.x) {
+        const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + i);
+        const u32x4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        u32x4 a, b;
+        a.x = m0.x | (m0.y << 8) | (m1.y << 16), a.y = m0.z, a.z = m0.w, a.w = m1.x;
+        b.x = m1.z, b.y = m1.w, b.z = m2.x, b.w = m0.x == RT_MAT_DIELECTRIC ? m2.z : m2.y;
+        mat[2u * i] = a, mat[2u * i + 1u] = b;
+    }
+}
+
 // ---- trace_ray (src/trace_ray.hpp:11-82), the part after rtcIntersect1 ------------------------------
 // Given the closest hit `h` of the ray (org, dir): returns true and sets `result` when the path ends
 // (miss -> att*(sky+rad); absorbed -> att*rad); otherwise updates org/dir/att and returns false.
 // `dir` is the unnormalised float direction.
-RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f3& dir, f3& att, f3& rad, f3& result) {
+// USE_TAB = false: kernels that stage no tables (the dense SHADE kernel, the probes)
+template <bool USE_TAB = false>
+RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, const Hit& h, f3& org, f3& dir, f3& att, f3& rad, f3& result) {
     if (h.tri == kNoTri) {
         result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
         return true;
@@ -611,14 +641,23 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
-    // The instance and material records are read WHOLE, here, as three 16-byte words each, and live in registers for the rest of the
-    // round: one memory round trip after the shading record's, then one for the texel. Read field by field at their uses (round 2) they
-    // became five more dependent fetches, each stuck behind a branch — the texture kind, the layer, the normal matrix after the first
-    // normalisation, the emission, the roughness — and a shading round is made of waiting: ~21,000 wave cycles against ~600 instructions.
-    const InstRec& inst = S.inst[S.packed_mat ? (iw & kPackedInstMask) : iw];
+    // wave-uniform: every hit of this round finds its material and its normal matrix in the staged tables (n_nm = n_mat = 0 without the packed word)
+    bool lds = false;
+    if (USE_TAB) lds = __builtin_amdgcn_ballot_w64(!((iw & kPackedInstMask) < tab.n_nm && (iw >> kPackedInstBits) < tab.n_mat)) == 0ull;
     MatRec mat;
-    {
-        const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + (S.packed_mat ? (iw >> kPackedInstBits) : inst.material));
+    const InstRec* inst = nullptr;
+    if (USE_TAB && __builtin_expect(lds, 1)) {
+        const uint32_t at = (iw >> kPackedInstBits) * 2u;
+        const u32x4 a = tab.mat[at], b = tab.mat[at + 1u];
+        mat.type = a.x & 0xffu, mat.tex_kind = (a.x >> 8) & 0xffu, mat.tex_layer = a.x >> 16;
+        mat.color[0] = __uint_as_float(a.y), mat.color[1] = __uint_as_float(a.z), mat.color[2] = __uint_as_float(a.w);
+        mat.emissive[0] = __uint_as_float(b.x), mat.emissive[1] = __uint_as_float(b.y), mat.emissive[2] = __uint_as_float(b.z);
+        mat.roughness = mat.ior = __uint_as_float(b.w);
+    } else {
+        // The material record is read WHOLE, here, as three 16-byte words: one memory round trip after the shading record's, then one for
+        // the texel. Read field by field at their uses (round 2) they became five more dependent fetches, each stuck behind a branch.
+        inst = S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw);
+        const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + (S.packed_mat ? (iw >> kPackedInstBits) : inst->material));
         const u32x4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
         mat.type = m0.x, mat.tex_kind = m0.y, mat.color[0] = __uint_as_float(m0.z), mat.color[1] = __uint_as_float(m0.w);
         mat.color[2] = __uint_as_float(m1.x), mat.tex_layer = m1.y, mat.emissive[0] = __uint_as_float(m1.z), mat.emissive[1] = __uint_as_float(m1.w);
@@ -628,12 +667,49 @@ RT_DEV bool shade_hit(const SceneDev& S, uint32_t& rng, const Hit& h, f3& org, f
     const float w = (1.0f - bx) - by;
     const float tu = (w * uv0x + bx * uv1x) + by * uv2x;
     const float tv = (w * uv0y + bx * uv1y) + by * uv2y;
-    uint32_t texel = 0;
-    if (albedo_is_texture(mat)) texel = albedo_fetch(S, mat, tu, tv); // in flight during everything below
+    // The texel fetch, UNCONDITIONAL: a lane without a texture reads the first word of its own shading record instead (a line it has just
+    // loaded) and ignores it. Under `if (textured)` the fetch sat in an exec-mask region of its own, and what hipcc would not move across
+    // that region's ends — the normal matrix's loads among it — was issued after the texel's and waited for BEHIND it (vector memory
+    // returns in order): the round paid the texel's latency with one normalisation to overlap it.
+    uint32_t texel;
+    {
+        float fu = tu - __builtin_floorf(tu);
+        float fv = tv - __builtin_floorf(tv);
+        int iu = (int)__builtin_floorf(fu * 512.0f);
+        int iv = (int)__builtin_floorf(fv * 512.0f);
+        iu = iu < 0 ? 0 : (iu > 511 ? 511 : iu);
+        iv = iv < 0 ? 0 : (iv > 511 ? 511 : iv);
+        const uint8_t* ta = S.tex + (((size_t)mat.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u;
+        if (!albedo_is_texture(mat)) ta = reinterpret_cast<const uint8_t*>(sp);
+        texel = *reinterpret_cast<const uint32_t*>(ta); // in flight during everything below
+    }
     const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237 (here: its operands die early)
     rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
     const f3 vn = normalize3((w * n0 + bx * n1) + by * n2);
-    const float* nm = inst.normal_mat;
+    float nm[9]; // the normal matrix, read where it is used: nine registers less while the texel is in flight
+    if (USE_TAB && __builtin_expect(lds, 1)) {
+        const uint32_t at = (iw & kPackedInstMask) * 3u;
+        const u32x4 a = tab.nm[at], b = tab.nm[at + 1u];
+        const uint32_t c = *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(tab.nm + at + 2u);
+        nm[0] = __uint_as_float(a.x), nm[1] = __uint_as_float(a.y), nm[2] = __uint_as_float(a.z), nm[3] = __uint_as_float(a.w);
+        nm[4] = __uint_as_float(b.x), nm[5] = __uint_as_float(b.y), nm[6] = __uint_as_float(b.z), nm[7] = __uint_as_float(b.w);
+        nm[8] = __uint_as_float(c);
+    } else {
+        // (loads and their wait in ONE asm statement: hipcc's wait-count pass would otherwise merge this branch's pending loads into the
+        // join below and make the LDS path wait for the TEXEL there — vmcnt counts in order — before it may touch the same registers)
+        u32x4 a, b;
+        uint32_t c;
+        asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                     "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                     "global_load_dword %2, %3, off offset:32\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(c)
+                     : "v"(inst)
+                     : "memory");
+        nm[0] = __uint_as_float(a.x), nm[1] = __uint_as_float(a.y), nm[2] = __uint_as_float(a.z), nm[3] = __uint_as_float(a.w);
+        nm[4] = __uint_as_float(b.x), nm[5] = __uint_as_float(b.y), nm[6] = __uint_as_float(b.z), nm[7] = __uint_as_float(b.w);
+        nm[8] = __uint_as_float(c);
+    }
     const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
                      (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
     const f3 normal = normalize3(g);

@@ -56,6 +56,13 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)}; \
     lds_stack[threadIdx.x] = kTravDone; /* entry 0 of every lane's stack: the sentinel an empty stack pops (rt_device.h: trav_pop_lds) */
 
+// ... and of a kernel that also shades: the head of the scene's normal-matrix and material tables (rt_device.h: ShadeTables). Before
+// RT_TRAVERSAL_LDS, whose barrier covers this fill too.
+#define RT_SHADE_LDS                                                                                   \
+    __shared__ u32x4 shade_nm[3 * kLdsNm], shade_mat[2 * kLdsMats];                                    \
+    shade_tables_fill(S, shade_nm, shade_mat);                                                         \
+    const ShadeTables tab{(lds_u32x4*)shade_nm, (lds_u32x4*)shade_mat, S.lds_nm, S.lds_mats};
+
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
 // the part of one bounce after the closest-hit query: unpack halves -> shade_hit -> repack (the body of
@@ -63,13 +70,14 @@ RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), 
 // FROM_TRAV (the kernels whose lanes keep a ray across shading rounds): origin and direction are READ from the traversal state — T.o
 // and T.d are r.org and h2f(r.dir) exactly, trav_begin put them there — so that r.org / r.dir are written here and consumed by the
 // trav_begin (or the queue store) that follows, live only inside the round: six lane registers less through the traversal loop.
+// (with `tab`: the kernel's staged shading tables; without: the memory path only)
 template <bool FROM_TRAV = false>
-RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr) {
+RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr, const ShadeTables* tab = nullptr) {
     f3 org = FROM_TRAV ? T->o : r.org;
     f3 dir = FROM_TRAV ? T->d : ray_dir(r);
     f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
     f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-    const bool done = shade_hit(S, rng, h, org, dir, att, rad, result);
+    const bool done = FROM_TRAV ? shade_hit<true>(S, *tab, rng, h, org, dir, att, rad, result) : shade_hit<false>(S, ShadeTables{}, rng, h, org, dir, att, rad, result);
     r.org = org;
     r.dir[0] = f2h(dir.x), r.dir[1] = f2h(dir.y), r.dir[2] = f2h(dir.z);
     r.att[0] = f2h(att.x), r.att[1] = f2h(att.y), r.att[2] = f2h(att.z);
@@ -171,6 +179,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     lds_f32* const color_b = color_g + kMegaBlock;
     RayState r{};
     Trav T;
+    RT_SHADE_LDS
     RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
     bool live = false;      // this lane owns a pixel with samples left
@@ -257,7 +266,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
         if (live && T.cur == kTravDone) {
             f3 res;
-            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
+            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab);
             depth++;
             bool killed = false;
             if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
@@ -551,8 +560,8 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
             const uint32_t tri = __float_as_uint(hits[i].w);
             kind = 0u;
             if (tri != kNoTri) {
-                const uint32_t inst_id = S.shade[tri].instance & (S.packed_mat ? kPackedInstMask : ~0u);
-                kind = 1u + (S.mats[S.inst[inst_id].material].type & 3u);
+                const uint32_t iw = S.shade[tri].instance;
+                kind = 1u + (S.mats[S.packed_mat ? (iw >> kPackedInstBits) : S.inst[iw].material].type & 3u);
             }
         }
         if (threadIdx.x < 8u) kind_count[threadIdx.x] = 0u;
@@ -710,6 +719,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     constexpr uint32_t kWavesPerBlock = kMegaBlock / 64;
     const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    RT_SHADE_LDS
     RT_TRAVERSAL_LDS(kMegaBlock)
     __shared__ unsigned long long rq_stage_mem[REQ ? kWavesPerBlock * kRqStage : 1u];
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
@@ -906,7 +916,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth)));
         if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
             f3 res;
-            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T);
+            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab);
             depth++;
             bool ends = done;
             if (done) {

@@ -1007,6 +1007,10 @@ int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scen
         s->dev.n_tris = (uint32_t)(s->hs.wverts.size() / 9);
         std::memcpy(s->dev.sky, s->hs.sky, 12);
         s->dev.packed_mat = s->hs.packed_mat ? 1u : 0u;
+        // what the shading kernels stage in LDS (rt_device.h: ShadeTables): the head of the distinct-matrix table and of the material table
+        const bool stage = s->hs.packed_mat && s->hs.n_layers <= 65536u; // (the staged material keeps its layer in 16 bits)
+        s->dev.lds_nm = stage ? (uint32_t)std::min<size_t>(s->hs.inst.size(), kLdsNm) : 0u;
+        s->dev.lds_mats = stage ? (uint32_t)std::min<size_t>(s->hs.mats.size(), kLdsMats) : 0u;
         for (int a = 0; a < 3; ++a) {
             const float ext = s->hs.bounds_hi[a] - s->hs.bounds_lo[a];
             s->dev.cell_lo[a] = s->hs.bounds_lo[a];

@@ -68,7 +68,13 @@ struct alignas(64) ShadeRec {
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec must be 64 bytes");
 
-// GeometryData::obj_to_world + material id (src/scene.hpp:17-24): 48 bytes
+// GeometryData::obj_to_world + material id (src/scene.hpp:17-24): 48 bytes.
+// Where the shading word is packed (above) the device table holds every DISTINCT normal matrix once, the one most triangles use first
+// (scene_build.cpp): a glTF scene has one instance per node and primitive and a handful of different matrices — the atrium 166 and 5 —
+// and shading reads the first kLdsNm of them, with the first kLdsMats materials, from LDS (rt_device.h: ShadeTables).
+// (A CU's 160 KB of LDS are handed out in 1,280-byte granules — measured: k_megakernel's three workgroups per CU fit up to 53,760 bytes each,
+// profiles/r05_lds_granule.txt — which leaves 1,216 bytes beside the staged tree top, the stacks and the colour sums: 8 x 48 + 24 x 32 = 1,152.)
+constexpr uint32_t kLdsNm = 8, kLdsMats = 24;
 struct alignas(16) InstRec {
     float normal_mat[9]; // column-major 3x3
     uint32_t material;
@@ -102,6 +108,7 @@ struct SceneDev {
     float sky[3];
     float cell_lo[3], cell_scale[3]; // ray re-ordering (f-3): cell = (origin - cell_lo) * cell_scale, 0..4 per axis over the scene's bounds
     uint32_t packed_mat;             // 1: ShadeRec::instance carries the material index in bits 20..31
+    uint32_t lds_nm, lds_mats;       // normal matrices / materials the shading kernels stage in LDS (0: shading word not packed)
 };
 
 // == Camera POD (src/camera.hpp:65-72)

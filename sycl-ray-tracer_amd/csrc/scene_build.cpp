@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <deque>
 #include <functional>
@@ -618,11 +619,43 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     hs.n_layers = d->n_layers;
     if (d->n_layers) hs.tex.assign(d->textures, d->textures + (size_t)d->n_layers * 512u * 512u * 4u);
     hs.packed_mat = d->n_instances <= (1u << kPackedInstBits) && d->n_materials <= (1u << (32u - kPackedInstBits));
-    hs.inst.resize(d->n_instances);
-    for (uint32_t i = 0; i < d->n_instances; ++i) {
-        std::memcpy(hs.inst[i].normal_mat, d->instances[i].normal_mat, sizeof(float) * 9);
-        hs.inst[i].material = d->instances[i].material;
-        hs.inst[i].pad[0] = hs.inst[i].pad[1] = 0;
+    // The device's instance table. Packed shading word (the rule, rt_types.h): the material index travels in the word, so what is left of an
+    // instance is its normal matrix — and a scene has far fewer DISTINCT matrices than instances (one instance per glTF node and primitive:
+    // 166 and 5 on the atrium). The table holds every distinct bit pattern once, ordered by the number of triangles that use it, so that the
+    // head of the table — what the shading kernels stage in LDS — covers the most hits. inst_slot[i]: instance i's row of the table.
+    std::vector<uint32_t> inst_slot(d->n_instances);
+    if (hs.packed_mat) {
+        std::vector<uint64_t> use(d->n_instances, 0);
+        for (uint32_t t = 0; t < d->n_triangles; ++t) use[d->tri_instance[t]]++;
+        std::map<std::array<uint32_t, 9>, uint32_t> seen; // bit pattern -> provisional row
+        std::vector<std::array<uint32_t, 9>> rows;
+        std::vector<uint64_t> row_use;
+        for (uint32_t i = 0; i < d->n_instances; ++i) {
+            std::array<uint32_t, 9> key;
+            std::memcpy(key.data(), d->instances[i].normal_mat, 36);
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                it = seen.emplace(key, (uint32_t)rows.size()).first;
+                rows.push_back(key), row_use.push_back(0);
+            }
+            inst_slot[i] = it->second;
+            row_use[it->second] += use[i];
+        }
+        std::vector<uint32_t> order(rows.size()), rank(rows.size());
+        for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return row_use[a] > row_use[b]; });
+        for (uint32_t k = 0; k < order.size(); ++k) rank[order[k]] = k;
+        hs.inst.assign(rows.size(), InstRec{});
+        for (uint32_t k = 0; k < rows.size(); ++k) std::memcpy(hs.inst[rank[k]].normal_mat, rows[k].data(), 36);
+        for (uint32_t i = 0; i < d->n_instances; ++i) inst_slot[i] = rank[inst_slot[i]];
+    } else {
+        hs.inst.resize(d->n_instances);
+        for (uint32_t i = 0; i < d->n_instances; ++i) {
+            std::memcpy(hs.inst[i].normal_mat, d->instances[i].normal_mat, sizeof(float) * 9);
+            hs.inst[i].material = d->instances[i].material;
+            hs.inst[i].pad[0] = hs.inst[i].pad[1] = 0;
+            inst_slot[i] = i;
+        }
     }
     hs.mats.resize(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -662,7 +695,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         std::memcpy(s.n2, d->normals + 3 * i2, 12);
         std::memcpy(s.uv0, d->uvs + 2 * i0, 8), std::memcpy(s.uv1, d->uvs + 2 * i1, 8);
         std::memcpy(s.uv2, d->uvs + 2 * i2, 8);
-        s.instance = hs.packed_mat ? (ii | (hs.inst[ii].material << kPackedInstBits)) : ii;
+        s.instance = hs.packed_mat ? (inst_slot[ii] | (d->instances[ii].material << kPackedInstBits)) : ii;
     }
     for (size_t i = 0; i < hs.wverts.size(); ++i) {
         if (!std::isfinite(hs.wverts[i])) { err = "non-finite world-space vertex"; return RT_ERR_INVALID; }
