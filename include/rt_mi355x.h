@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 7
+#define RT_ABI_VERSION 8
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -224,6 +224,12 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
  *                       compacts the survivors into the next queue — shoot_rays as the reference has it (src/render_wavefront.cpp:222-312)
  *                       — instead of the EXTEND + SHADE pair with its hit-record round trip. reorder / matsort act in k_wf_shade and
  *                       are ignored then.
+ *   pixel_slices        MEGAKERNEL renderers (the only field they use). A pixel's samples are a sequential chain (one RNG word), but not
+ *                       bound to one lane: the chain is cut into slices of decreasing length, all first slices are rendered, then all
+ *                       second ones ..., the pixel's colour sum and RNG word travelling through memory in between, so that the frame
+ *                       drains over its last, short slices instead of over whole pixels (bit-identical frame). -1 = automatic (as many
+ *                       as the tile's size calls for; one for a tile of at most ~1.25 pixels per resident lane), 0 or 1 = off,
+ *                       2 .. 8 = that many. rt_stats.pixel_slices reports what ran.
  * The environment variables RT_WF_FINISH_DEPTH / _SAMPLES_PER_LAUNCH / _STREAMS / _REQUEUE / _REORDER / _MATSORT / _LPT /
  * _GRAPH still work: rt_renderer_create turns them into the initial rt_schedule (a shim for scripts; tests use the API). */
 #define RT_SCHED_ALL_BOUNCES 0xFFFFFFFFu
@@ -237,8 +243,9 @@ typedef struct rt_schedule {
     int32_t cost_order;
     uint32_t hip_graph;
     uint32_t fused_bounce;
+    int32_t pixel_slices; /* (ABI 8) megakernel */
 } rt_schedule;
-/* Megakernel renderers accept the call and ignore every field. No frame may be in flight; the tile's queues are re-allocated. */
+/* Megakernel renderers accept the call and use pixel_slices only. No frame may be in flight; the tile's queues are re-allocated. */
 int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s);
 int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out);
 
@@ -282,7 +289,7 @@ typedef struct rt_stats {
      * renderer was created, 4 (HIP's default) when unset. The library never changes the environment; an automatic stream-lane count is resolved
      * down to lanes + 2 <= hw_queues (the frame's stream and one stream of the host framework beside the lanes'), see stream_lanes above. */
     uint32_t hw_queues;
-    uint32_t reserved0;
+    uint32_t pixel_slices; /* (ABI 8) megakernel: slices a pixel's samples were rendered in (1 = every pixel on one lane) */
 } rt_stats;
 
 /* == IRenderer::render_frame(camera, scene) (src/render_megakernel.cpp:75-187,

@@ -628,9 +628,26 @@ RT_DEV void shade_tables_fill(const SceneDev& S, u32x4* nm, u32x4* mat) { // coo
 // Given the closest hit `h` of the ray (org, dir): returns true and sets `result` when the path ends
 // (miss -> att*(sky+rad); absorbed -> att*rad); otherwise updates org/dir/att and returns false.
 // `dir` is the unnormalised float direction.
+// Diagnostic builds only (scripts/build_variant.sh NAME -DRT_ROUND_STAMPS): cycle stamps inside a shading round. `ck` points at eight wave-uniform
+// accumulators (scalar registers), ck[7] = the previous stamp; RT_STAMP_AFTER adds the cycles since then to ck[i] once VAL is in its register
+// (a stamp is a scalar memory round trip, ~300 cycles: the shares are what counts, not the sum).
+#ifdef RT_ROUND_STAMPS
+#define RT_STAMP_AFTER(ck, i, VAL)                                                     \
+    do {                                                                              \
+        if (ck) {                                                                     \
+            asm volatile("" ::"v"(VAL));                                              \
+            const long long n_ = (long long)__builtin_readcyclecounter();             \
+            (ck)[i] += n_ - (ck)[7];                                                  \
+            (ck)[7] = n_;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define RT_STAMP_AFTER(ck, i, VAL) do { } while (0)
+#endif
 // USE_TAB = false: kernels that stage no tables (the dense SHADE kernel, the probes)
 template <bool USE_TAB = false>
-RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, const Hit& h, f3& org, f3& dir, f3& att, f3& rad, f3& result) {
+RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, const Hit& h, f3& org, f3& dir, f3& att, f3& rad, f3& result,
+                      long long* ck = nullptr) {
     if (h.tri == kNoTri) {
         result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
         return true;
@@ -641,6 +658,7 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
     const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
     const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
     const uint32_t iw = __float_as_uint(s3.w); // instance (| material << 20: rt_types.h)
+    RT_STAMP_AFTER(ck, 1, iw); // the shading record has arrived
     // wave-uniform: every hit of this round finds its material and its normal matrix in the staged tables (n_nm = n_mat = 0 without the packed word)
     bool lds = false;
     if (USE_TAB) lds = __builtin_amdgcn_ballot_w64(!((iw & kPackedInstMask) < tab.n_nm && (iw >> kPackedInstBits) < tab.n_mat)) == 0ull;
@@ -682,6 +700,7 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
         const uint8_t* ta = S.tex + (((size_t)mat.tex_layer * 512u + (size_t)iv) * 512u + (size_t)iu) * 4u;
         if (!albedo_is_texture(mat)) ta = reinterpret_cast<const uint8_t*>(sp);
         texel = *reinterpret_cast<const uint32_t*>(ta); // in flight during everything below
+        RT_STAMP_AFTER(ck, 2, ta); // material read, uv interpolated, texel fetch issued
     }
     const bool emits = mat.type == RT_MAT_DIFFUSE || mat.type == RT_MAT_METALLIC; // Material::emitted :226-237 (here: its operands die early)
     rad = rad + (emits ? mk3(mat.emissive[0], mat.emissive[1], mat.emissive[2]) : mk3(0.0f, 0.0f, 0.0f));
@@ -713,8 +732,14 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
     const f3 g = mk3((nm[0] * vn.x + nm[3] * vn.y) + nm[6] * vn.z, (nm[1] * vn.x + nm[4] * vn.y) + nm[7] * vn.z,
                      (nm[2] * vn.x + nm[5] * vn.y) + nm[8] * vn.z);
     const f3 normal = normalize3(g);
+    RT_STAMP_AFTER(ck, 3, normal.x); // normal interpolated, transformed, normalised twice
     f3 sdir, satt;
-    if (scatter<true>(S, mat, rng, d, normal, tu, tv, sdir, satt, texel)) {
+#ifdef RT_SCATTER_PRIO
+    __builtin_amdgcn_s_setprio(RT_SCATTER_PRIO);
+#endif
+    const bool scattered = scatter<true>(S, mat, rng, d, normal, tu, tv, sdir, satt, texel);
+    RT_STAMP_AFTER(ck, 4, satt.x); // scatter, with the texel's arrival
+    if (scattered) {
         org = mk3(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
         dir = sdir;
         att = att * satt;

@@ -9,6 +9,8 @@
 //                     WavefrontRenderer's default schedule, one launch per frame (:222-354, 396-417)
 //   k_wf_resolve   == K6 convert_image_to_srgb + K7 write_image (:377-390, src/util.hpp:16-23)
 #pragma once
+#include <cstddef>
+
 #include "rt_device.h"
 
 namespace rt {
@@ -72,12 +74,13 @@ RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), 
 // trav_begin (or the queue store) that follows, live only inside the round: six lane registers less through the traversal loop.
 // (with `tab`: the kernel's staged shading tables; without: the memory path only)
 template <bool FROM_TRAV = false>
-RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr, const ShadeTables* tab = nullptr) {
+RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr, const ShadeTables* tab = nullptr,
+                         long long* ck = nullptr) {
     f3 org = FROM_TRAV ? T->o : r.org;
     f3 dir = FROM_TRAV ? T->d : ray_dir(r);
     f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
     f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-    const bool done = FROM_TRAV ? shade_hit<true>(S, *tab, rng, h, org, dir, att, rad, result) : shade_hit<false>(S, ShadeTables{}, rng, h, org, dir, att, rad, result);
+    const bool done = FROM_TRAV ? shade_hit<true>(S, *tab, rng, h, org, dir, att, rad, result, ck) : shade_hit<false>(S, ShadeTables{}, rng, h, org, dir, att, rad, result);
     r.org = org;
     r.dir[0] = f2h(dir.x), r.dir[1] = f2h(dir.y), r.dir[2] = f2h(dir.z);
     r.att[0] = f2h(att.x), r.att[1] = f2h(att.y), r.att[2] = f2h(att.z);
@@ -117,6 +120,9 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 // arithmetic and its order are unchanged (bit-exact with the per-pixel loops of the reference).
 // Tuning constants of the persistent traversal kernels (k_megakernel, k_wf_finish). Each was swept on the atrium and the voxel terrain;
 // the sweeps are in EXPERIMENTS.md.
+#ifndef RT_ROUND_PRIO
+#define RT_ROUND_PRIO 0
+#endif
 constexpr uint32_t kMegaBlock = 512;   // threads per workgroup: 8 independent waves share one LDS copy of the top of the BVH
 constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compiled for (80 VGPRs): 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
 constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
@@ -152,18 +158,82 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
         }
     }
 };
-template <bool STATS>
-__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, CameraDev cam, TileDev tile, uint32_t max_depth,
-                                                    uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
+// Pixel slices (round 5). A pixel's samples are one sequential chain — its RNG word runs on from sample to sample
+// (src/render_megakernel.cpp:146-153) — and a lane that takes a pixel is busy for ~520 rays, ~20 ms of the 1080p atrium frame: when the
+// cursor reaches the frame's last pixel every lane is somewhere inside such a chain, and the frame's last fifth is a drain in which the
+// machine empties lane by lane (profiles/r04_wave_stats.txt: queue empty after 105.7 of 129.9 ms). The chain has to stay sequential, but
+// not on ONE lane: it is cut into a few SLICES of decreasing length (e.g. 45 + 15 + 4 samples), the cursor hands out all first slices,
+// then all second ones, and so on, and the lane that finishes a slice stores the pixel's state — colour sum and RNG word, 32 bytes —
+// for whichever lane takes the next slice. The frame then drains over the length of the LAST slice. Per pixel the operations and their
+// order are untouched: same RNG sequence, same additions in the same order, bit-identical frame.
+//   state : per pixel of the tile two 16-byte words {sum r, g, b, tag} {RNG word, tag, -, -}, each written with ONE write-through
+//           (sc1) store and read with an sc1 load: a word is seen whole, and a reader takes the state only if BOTH tags say "written
+//           for slice j of this frame" (tag0 + j; tag0 grows from frame to frame, the buffer is never cleared).
+//   order : slot q of the cursor = slice q / n_slots of pixel slot q % n_slots, so slice j of a pixel is handed out a whole sweep of the
+//           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it (rt_frame:
+//           mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) polls once per iteration of its
+//           wave's loop without holding the wave up. No lane ever waits for a LATER slot: nothing can deadlock.
+constexpr uint32_t kMaxSlices = 8;
+struct SliceDev {
+    u32x4* state;
+    uint32_t n_slices;        // 1: a lane keeps its pixel for all its samples
+    uint32_t tag0;
+    uint32_t bound[kMaxSlices]; // slice j renders samples bound[j - 1] (0 for j = 0) ... bound[j] - 1; bound[n_slices - 1] = spp
+};
+// The frame's constants that only a shading round or a refill reads — the camera's twelve floats, the slices — live in DEVICE memory and are
+// loaded where they are used (scalar loads, hot in the scalar cache): as kernel arguments hipcc kept them in ~35 scalar registers through the
+// traversal loop, in a kernel that has none to spare (with the slices on top: 38 scalar registers spilled into vector lanes, 46 vector
+// registers into scratch, 122 -> 145 ms). frame_now() hides the pointer's origin from the compiler, or it would hoist the loads out of the
+// wave's loop again.
+struct MegaFrame {
+    CameraDev cam;
+    SliceDev sl;
+};
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, n_slices) == 8 && offsetof(SliceDev, bound) == 16, "frame_* below read MegaFrame by byte offset");
+RT_DEV CameraDev frame_camera(const MegaFrame* f, int32_t width, int32_t height) { // the twelve floats as three scalar loads, here and now
+    u32x4 a, b, c;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\t"
+                 "s_load_dwordx4 %1, %3, 0x10\n\t"
+                 "s_load_dwordx4 %2, %3, 0x20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c)
+                 : "s"(f)); // (no memory clobber: the frame's constants are written by nobody while the kernel runs, and a clobber would pin every
+                            // variable a lambda captures by reference to scratch memory)
+    CameraDev cam;
+    cam.center[0] = __uint_as_float(a.x), cam.center[1] = __uint_as_float(a.y), cam.center[2] = __uint_as_float(a.z);
+    cam.pixel00[0] = __uint_as_float(a.w), cam.pixel00[1] = __uint_as_float(b.x), cam.pixel00[2] = __uint_as_float(b.y);
+    cam.du[0] = __uint_as_float(b.z), cam.du[1] = __uint_as_float(b.w), cam.du[2] = __uint_as_float(c.x);
+    cam.dv[0] = __uint_as_float(c.y), cam.dv[1] = __uint_as_float(c.z), cam.dv[2] = __uint_as_float(c.w);
+    cam.width = width, cam.height = height;
+    return cam;
+}
+struct SliceNow { // {state pointer, -, tag0} and the bounds, as loaded
+    u32x4 head;  // state lo, state hi, n_slices, tag0
+    u32x8 bound;
+};
+RT_DEV SliceNow frame_slices(const MegaFrame* f) {
+    SliceNow n;
+    asm volatile("s_load_dwordx4 %0, %2, 0x38\n\t"
+                 "s_load_dwordx8 %1, %2, 0x48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(n.head), "=&s"(n.bound)
+                 : "s"(f));
+    return n;
+}
+template <bool STATS, bool SLICED>
+__global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, const MegaFrame* frame, int32_t width, int32_t height, TileDev tile,
+                                                    uint32_t max_depth, uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
                                                     unsigned long long* __restrict__ ray_counter,
-                                                    unsigned long long* __restrict__ stats_out) {
+                                                    unsigned long long* __restrict__ stats_out, uint32_t n_slices) {
     WaveStats ws;
     long long t_begin = 0, t_mark = 0, t_trav = 0, t_shade = 0;
+    long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // RT_ROUND_STAMPS builds: cycles between the stamps of a shading round
     if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
     unsigned long long wall_begin = 0, wall_exhausted = 0;
     if (STATS) wall_begin = wall_clock64(); // 100 MHz, the same counter on every CU
-    const uint32_t tiles_x = (uint32_t)(cam.width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
+    const uint32_t tiles_x = (uint32_t)(width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)(threadIdx.x & 63u);
     uint32_t* pixel_cursor = reinterpret_cast<uint32_t*>(ray_counter + 1);
@@ -182,22 +252,36 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     RT_SHADE_LDS
     RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
-    bool live = false;      // this lane owns a pixel with samples left
+    // A lane is `live` when it owns a pixel slice with samples left; `depth` then holds the bounces of its current path so far — or, in a
+    // SLICED launch, kPend | j: the lane has taken slice j > 0 of a pixel and waits for the state slice j - 1 ends with. It LOOKS for that
+    // state in every shading round of its wave, where a ray is started anyway (a waiting lane counts as one that waits for shading, so rounds
+    // keep coming). A state poll of its own beside the refill, with its own copy of the camera-ray code and its own way round the wave's
+    // loop, cost more registers than the kernel has: 51 spilled, 122 -> 145 ms.
+    constexpr uint32_t kPend = 0x40000000u;
+    bool live = false;
     RefillPolicy refill;    // idle lanes that trigger a pixel fetch: set per wave from the pixels it finishes
     bool exhausted = false; // wave-uniform: the frame's pixel cursor has passed the last slot
+    uint32_t slice_j = 0;   // wave-uniform: the slice the cursor was in at this wave's last claim
+    auto state_rsrc = [&](const SliceNow& n) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)n.head.y << 32) | n.head.x), 0, (int)((uint32_t)tile.local_rows * (uint32_t)width * 32u), 0x00020000);
+    };
     // (ONE frame-wide cursor. Round 1 cut the frame into a region per XCD, for L2 locality: +4 % then, -2 % ... -16 % once the kernel was bound
     // by instruction issue — all waves should advance over one front, or the frame's last pixels all lie in the slowest region. EXPERIMENTS.md)
-    auto start_pixel = [&](uint32_t p) { // pixel slot p (8x8-tile order) becomes this lane's pixel; slots outside the image are skipped
+    auto take_slot = [&](uint32_t p, uint32_t j) { // slice j of pixel slot p (8x8-tile order) becomes this lane's; slots outside the image are skipped
         const uint32_t t = p >> 6; // (slots in row order instead of 8x8 blocks: +-0 on both scenes)
         x = (int)((t % tiles_x) * 8u + (p & 7u));
         ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
         gy = tile_global_row(tile, ly);
-        if (x < cam.width && ly < tile.local_rows && gy < cam.height) {
-            rng = pixel_seed(x, gy, cam.width, cam.height, seed_mode);
-            *color_r = 0.0f, *color_g = 0.0f, *color_b = 0.0f;
-            s = 0, depth = 0;
-            r = camera_ray(cam, x, gy, rng);
-            trav_begin(T, r.org, ray_dir(r), stack);
+        if (x < width && ly < tile.local_rows && gy < height) {
+            if (!SLICED || j == 0) {
+                rng = pixel_seed(x, gy, width, height, seed_mode);
+                *color_r = 0.0f, *color_g = 0.0f, *color_b = 0.0f;
+                s = 0, depth = 0;
+                r = camera_ray(frame_camera(frame, width, height), x, gy, rng);
+                trav_begin(T, r.org, ray_dir(r), stack);
+            } else {
+                depth = kPend | j;
+            }
             live = true;
         }
     };
@@ -208,15 +292,15 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     // nothing on 1/2 and 1/4 of the frame: there idle lanes refill, and the tail is a single chain.)
     {
         const uint32_t n_waves = gridDim.x * (kMegaBlock / 64u);
-        if (n_slots <= n_waves * 64u) {
+        if (n_slots <= n_waves * 64u && n_slices == 1u) {
             const uint32_t p = (uint32_t)lane * n_waves + blockIdx.x * (kMegaBlock / 64u) + (threadIdx.x >> 6);
-            if (p < n_slots) start_pixel(p);
+            if (p < n_slots) take_slot(p, 0u);
             exhausted = true;
             if (STATS) wall_exhausted = wall_clock64();
         }
     }
     for (;;) {
-        // REFILL: idle lanes take the next pixels from the frame-wide cursor, one atomic per wave and round.
+        // REFILL: idle lanes take the next slots from the frame-wide cursor, one atomic per wave and round.
         // A wave is persistent: it keeps pulling pixels until the frame is exhausted, so a lane whose
         // pixel was cheap (sky) does not idle while its neighbours finish 640-ray pixels.
         if (!exhausted) {
@@ -226,10 +310,16 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (SLICED)
+                    while (slice_j + 1u < n_slices && base >= (slice_j + 1u) * n_slots) slice_j++; // (the cursor only moves forward)
+                const uint32_t slice_base = SLICED ? slice_j * n_slots : 0u, total_slots = SLICED ? n_slots * n_slices : n_slots;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                const uint32_t p = base + rank;
-                if (!live && p < n_slots) start_pixel(p);
-                if (base + cnt >= n_slots) {
+                const uint32_t q = base + rank;
+                if (!live && q < total_slots) {
+                    const bool next = SLICED && q - slice_base >= n_slots; // a claim of at most 64 slots crosses at most one slice boundary
+                    take_slot(next ? q - slice_base - n_slots : q - slice_base, next ? slice_j + 1u : slice_j);
+                }
+                if (base + cnt >= total_slots) {
                     exhausted = true;
                     if (STATS) wall_exhausted = wall_clock64();
                 }
@@ -261,33 +351,83 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             t_trav += now - t_mark, t_mark = now;
         }
         // SHADE the lanes whose traversal is complete
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(RT_ROUND_PRIO);
+#ifdef RT_ROUND_STAMPS
+        if (STATS) ck[7] = (long long)__builtin_readcyclecounter();
+#endif
         bool pixel_finished = false;
-        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone)); // every lane of the round traces one ray
+        {
+            const unsigned long long traced = __ballot(live && T.cur == kTravDone && depth < kPend); // every lane of the round but those that wait for a state has traced a ray
+            wave_rays += (unsigned long long)__popcll(traced);
+            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(8); // only lanes that wait for a state (small tiles): do not spin at full speed
+        }
         if (live && T.cur == kTravDone) {
-            f3 res;
-            const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab);
-            depth++;
-            bool killed = false;
-            if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
-            if (done || killed || depth == max_depth) {
-                if (done) *color_r = *color_r + res.x, *color_g = *color_g + res.y, *color_b = *color_b + res.z; // paths that outlive max_depth add (0,0,0)
-                s++;
-                depth = 0;
-                if (s < spp) {
-                    r = camera_ray(cam, x, gy, rng);
-                } else { // pixel finished: mean, sqrt gamma, fp32 + unorm8 stores (src/render_megakernel.cpp:154-158)
-                    live = false, pixel_finished = true;
-                    const float n = (float)spp;
-                    const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
-                    const size_t o = ((size_t)ly * (size_t)cam.width + (size_t)x);
-                    if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
-                    if (out_u8)
-                        reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
-                                                                 ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+            bool start = false; // this lane starts a path: a camera ray (src/render_megakernel.cpp:148-151)
+            if (SLICED && depth >= kPend) { // the state of the pixel: two 16-byte words, taken when both carry this slice's tag
+                const SliceNow sn = frame_slices(frame);
+                const auto rsrc = state_rsrc(sn);
+                const uint32_t j = depth & 0xFFu;
+                const uint32_t at = ((uint32_t)ly * (uint32_t)width + (uint32_t)x) * 32u, tag = sn.head.w + j;
+                const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
+                const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
+                if (w0.w == tag && w1.y == tag) {
+                    *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.y), *color_b = __uint_as_float(w0.z);
+                    rng = w1.x;
+                    s = sn.bound[0]; // (j >= 1: the slice starts with sample bound[j - 1])
+#pragma unroll
+                    for (uint32_t k = 1; k + 1u < kMaxSlices; ++k)
+                        if (j == k + 1u) s = sn.bound[k];
+                    start = true;
+                }
+            } else {
+                f3 res;
+                const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS ? ck : nullptr);
+#ifdef RT_TAIL_PRIO
+                __builtin_amdgcn_s_setprio(RT_TAIL_PRIO);
+#endif
+                depth++;
+                bool killed = false;
+                if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
+                if (done || killed || depth == max_depth) {
+                    if (done) *color_r = *color_r + res.x, *color_g = *color_g + res.y, *color_b = *color_b + res.z; // paths that outlive max_depth add (0,0,0)
+                    s++;
+                    uint32_t handed = 0; // the slice that starts with sample s, if this sample was the last of its slice
+                    SliceNow sn{};
+                    if (SLICED) {
+                        sn = frame_slices(frame);
+#pragma unroll
+                        for (uint32_t k = 0; k + 1u < kMaxSlices; ++k) // (the bounds beyond the last slice repeat spp)
+                            if (s == sn.bound[k] && s < spp) handed = k + 1u;
+                    }
+                    if (SLICED && handed) { // the pixel goes on in another lane: its state, tagged for that slice
+                        live = false, pixel_finished = true;
+                        const auto rsrc = state_rsrc(sn);
+                        const uint32_t at = ((uint32_t)ly * (uint32_t)width + (uint32_t)x) * 32u, tag = sn.head.w + handed;
+                        u32x4 w0, w1;
+                        w0.x = __float_as_uint(*color_r), w0.y = __float_as_uint(*color_g), w0.z = __float_as_uint(*color_b), w0.w = tag;
+                        w1.x = rng, w1.y = tag, w1.z = 0u, w1.w = 0u;
+                        __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, (int)at, 0, 16 /* sc1 */);
+                        __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
+                    } else if (s < spp) {
+                        start = true;
+                    } else { // pixel finished: mean, sqrt gamma, fp32 + unorm8 stores (src/render_megakernel.cpp:154-158)
+                        live = false, pixel_finished = true;
+                        const float n = (float)spp;
+                        const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
+                        const size_t o = ((size_t)ly * (size_t)width + (size_t)x);
+                        if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                        if (out_u8)
+                            reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
+                                                                     ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
+                    }
                 }
             }
-            if (live) trav_begin(T, r.org, ray_dir(r), stack);
+            if (start) {
+                depth = 0;
+                r = camera_ray(frame_camera(frame, width, height), x, gy, rng);
+            }
+            if (live && depth < kPend) trav_begin(T, r.org, ray_dir(r), stack);
+            RT_STAMP_AFTER((STATS ? ck : nullptr), 5, T.ox); // sky lanes, half conversions, path ends, camera rays, trav_begin
         }
         refill.round(pixel_finished);
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
@@ -307,6 +447,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         atomicMin(stats_out + 13, wall_begin);
         if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
         atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
+#ifdef RT_ROUND_STAMPS
+        for (int i = 1; i <= 5; ++i) atomicAdd(stats_out + 15 + i, (unsigned long long)ck[i]);
+#endif
     }
 }
 

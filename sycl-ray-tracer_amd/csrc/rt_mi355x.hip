@@ -140,6 +140,10 @@ struct rt_renderer {
     uint8_t* d_u8 = nullptr;
     // megakernel
     unsigned long long* d_ray_counter = nullptr;
+    u32x4* d_slice_state = nullptr;        // pixel slices (rt_kernels.h: SliceDev): 32 bytes per pixel of the tile, zero when allocated, never cleared
+    MegaFrame* d_frame = nullptr;          // the frame's constants k_megakernel reads from device memory: camera + slices (copied per frame from h_frame, pinned)
+    MegaFrame* h_frame = nullptr;
+    uint32_t slice_tag = 0;                // tag0 of the last frame (grows by kMaxSlices per frame)
     uint32_t rr_start = 0;                 // Russian roulette from this bounce on (0 = off, the reference's behaviour)
     unsigned long long* d_stats = nullptr; // RT_KERNEL_STATS=1: wave scheduling statistics (diagnostic)
     // wavefront: the tile is rendered as K interleaved sub-tiles ("lanes"), each with its own queues and
@@ -192,7 +196,7 @@ struct rt_renderer {
     //   their paths; >= max_depth = the reference's schedule (a launch pair per bounce).
     //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
     //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
-    rt_schedule sched{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u};
+    rt_schedule sched{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u, -1};
     // waves per SIMD one k_wf_extend launch asks for; 0 = all 8 on one stream lane, 4 (one 1024-thread workgroup per CU) where lanes overlap: the
     // lanes' launches then sit side by side instead of queueing workgroups behind each other (3 lanes: 190.4 -> 186.7 ms per frame, 2 lanes 205.0 ->
     // 199.0; 2 / 6 waves: 201.6 / 190.8). RT_WF_EXTEND_OCC, tuning
@@ -244,7 +248,7 @@ void free_tile_buffers(rt_renderer* r) {
         if (p) (void)hipFree((void*)p);
         p = nullptr;
     };
-    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats);
+    fr(r->d_f32), fr(r->d_u8), fr(r->d_ray_counter), fr(r->d_stats), fr(r->d_slice_state);
     for (auto& L : r->lanes) {
         fr(L.d_rng), fr(L.d_accum), fr(L.d_counts), fr(L.d_hits), fr(L.d_rq_entries), fr(L.d_rq_ctl), fr(L.d_extra), fr(L.d_cost), fr(L.d_tile_key), fr(L.d_tile_order);
         for (auto& q : L.q) fr(q.org_id), fr(q.a), fr(q.b), fr(q.c);
@@ -413,6 +417,12 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
     HIPCHK(hipStreamSynchronize(r->stream));
     if (r->kind == RT_RENDERER_MEGAKERNEL) {
         HIPCHK(dalloc((void**)&r->d_ray_counter, 8 * sizeof(unsigned long long))); // [0] ray count, [1] the frame's pixel cursor (low word)
+        if (r->sched.pixel_slices != 0 && r->sched.pixel_slices != 1 && (uint64_t)n * 32u < (1ull << 31)) { // (the kernel addresses the state with 32-bit offsets)
+            HIPCHK(dalloc((void**)&r->d_slice_state, n * 32));
+            HIPCHK(hipMemsetAsync(r->d_slice_state, 0, n * 32, r->stream));
+            HIPCHK(hipStreamSynchronize(r->stream));
+            r->slice_tag = 0;
+        }
     } else {
         const uint32_t K = wf_stream_lanes(r);
         const bool per_bounce = r->sched.finish_depth > 0 && r->max_depth > 0; // EXTEND + SHADE launch pairs: the second queue and the hit records
@@ -474,6 +484,40 @@ int alloc_tile_buffers(rt_renderer* r) {
         g_err = msg;
     }
     return rc;
+}
+
+// Pixel slices of a megakernel frame (rt_kernels.h: SliceDev). G = pixel slots per resident lane, the frame's "generations". Slice j + 1 of a
+// pixel is handed out one sweep of the cursor after slice j, and a sweep over slices of length f takes G x f: the next slice is ready as long
+// as slices shrink by less than G from one to the next — by G / 1.5 here, at most 4, for the spread of the pixels' costs. The frame drains
+// over its LAST slice (1/32 of the samples where the slice count allows), instead of over a whole pixel.
+//   G <= 1.25 : one slice — nothing is handed out after the first generation, a slice would only wait for the one before it
+//   forced    : rt_schedule::pixel_slices >= 2 slices of that geometry whatever G is (tests, sweeps)
+SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint32_t tag0) {
+    SliceDev sl{};
+    sl.state = r->d_slice_state, sl.n_slices = 1, sl.tag0 = tag0;
+    for (uint32_t k = 0; k < kMaxSlices; ++k) sl.bound[k] = r->spp;
+    const int32_t want = r->sched.pixel_slices;
+    const double G = (double)n_slots / ((double)grid * kMegaBlock);
+    if (!r->d_slice_state || want == 0 || want == 1 || r->spp < 2 || (want < 0 && G <= 1.25)) return sl;
+    const double ratio = std::min(4.0, std::max(1.0, G / 1.5));
+    const double last = std::max(1.0, r->spp / 32.0);
+    uint32_t n = want >= 2 ? (uint32_t)want : (ratio > 1.05 ? 1u + (uint32_t)std::ceil(std::log(r->spp / last) / std::log(ratio)) : kMaxSlices);
+    n = std::min(std::min(n, kMaxSlices), r->spp);
+    double wsum = 0.0;
+    for (uint32_t i = 0; i < n; ++i) wsum += std::pow(ratio, (double)(n - 1 - i));
+    // sizes from the last slice up, each at least one sample; the first slice takes what is left
+    std::vector<uint32_t> size(n, 1u);
+    uint32_t used = 0;
+    for (uint32_t i = n; i-- > 1;) {
+        size[i] = std::max<uint32_t>(1u, (uint32_t)std::lround(r->spp * std::pow(ratio, (double)(n - 1 - i)) / wsum));
+        size[i] = std::min(size[i], r->spp - used - i); // leave one sample for every earlier slice
+        used += size[i];
+    }
+    size[0] = r->spp - used;
+    uint32_t b = 0;
+    for (uint32_t i = 0; i < n; ++i) b += size[i], sl.bound[i] = b;
+    sl.n_slices = n;
+    return sl;
 }
 
 CameraDev to_dev(const rt_camera& c) {
@@ -721,11 +765,23 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
         const uint32_t pad = r->mega_lds_pad;
         if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
         }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
+        if (r->slice_tag > 0xFFFFFF00u && r->d_slice_state) { // the tags are about to wrap (after 2^29 frames): start over from a cleared buffer
+            HIPCHK(hipMemsetAsync(r->d_slice_state, 0, (size_t)r->n_local * 32, st));
+            r->slice_tag = 0;
+        }
+        r->slice_tag += kMaxSlices;
+        const SliceDev sl = mega_slices(r, grid, tiles_x * tiles_y * 64u, r->slice_tag);
+        if (stats) stats->pixel_slices = sl.n_slices;
+        // (h_frame is rewritten per frame: the previous frame of this renderer has been collected, frame_begin refuses a second one in flight)
+        r->h_frame->cam = c, r->h_frame->sl = sl;
+        HIPCHK(hipMemcpyAsync(r->d_frame, r->h_frame, sizeof(MegaFrame), hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(e0, st));
         if (r->max_depth == 0) {
             hipLaunchKernelGGL(k_fill_black, dim3((r->n_local + 255u) / 256u), dim3(256), 0, st, r->n_local, d_f32, d_u8);
@@ -733,11 +789,15 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
             HIPCHK(hipMemsetAsync(r->d_stats, 0, 13 * sizeof(unsigned long long), st));
             HIPCHK(hipMemsetAsync(r->d_stats + 13, 0xff, 2 * sizeof(unsigned long long), st)); // the two atomicMin slots
             HIPCHK(hipMemsetAsync(r->d_stats + 15, 0, 9 * sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, r->d_stats);
+#define RT_MEGA_LAUNCH(ST, SL)                                                                                                                    \
+    hipLaunchKernelGGL((k_megakernel<ST, SL>), dim3(grid), dim3(kMegaBlock), pad, st, S, r->d_frame, c.width, c.height, r->tile, r->max_depth, r->spp, \
+                       r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, ST ? r->d_stats : (unsigned long long*)nullptr, sl.n_slices)
+            if (sl.n_slices > 1u) RT_MEGA_LAUNCH(true, true);
+            else RT_MEGA_LAUNCH(true, false);
         } else {
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(kMegaBlock), pad, st, S, c, r->tile, r->max_depth,
-                               r->spp, r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, (unsigned long long*)nullptr);
+            if (sl.n_slices > 1u) RT_MEGA_LAUNCH(false, true);
+            else RT_MEGA_LAUNCH(false, false);
+#undef RT_MEGA_LAUNCH
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
@@ -892,6 +952,9 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                          "%.0f cycles per traversal step, %.0f per shade round\n",
                          h[10], (double)h[8] / h[10], h[9], 100.0 * h[11] / h[8], 100.0 * h[12] / h[8],
                          (h[0] + h[2]) ? (double)h[11] / (h[0] + h[2]) : 0.0, h[4] ? (double)h[12] / h[4] : 0.0);
+        if (h[10] && h[4] && (h[16] | h[17] | h[18] | h[19] | h[20])) // RT_ROUND_STAMPS builds
+            std::fprintf(stderr, "[rt stats] shade round, cycles between stamps: record arrived %.0f | material + texel issued %.0f | normal %.0f | scatter + texel arrived %.0f | rest of the round %.0f\n",
+                         (double)h[16] / h[4], (double)h[17] / h[4], (double)h[18] / h[4], (double)h[19] / h[4], (double)h[20] / h[4]);
         if (h[10] && h[15] > h[13] && h[14] != ~0ull)
             std::fprintf(stderr, "[rt stats] frame timeline: %.2f ms in all, pixel queue empty after %.2f ms, drain %.2f ms (%.1f%%)\n",
                          (h[15] - h[13]) * 1e-5, (h[14] - h[13]) * 1e-5, (h[15] - h[14]) * 1e-5, 100.0 * (h[15] - h[14]) / (h[15] - h[13]));
@@ -1120,6 +1183,10 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_tile_read, hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+    if (kind == RT_RENDERER_MEGAKERNEL) {
+        if (hipMalloc((void**)&r->d_frame, sizeof(MegaFrame)) != hipSuccess || hipHostMalloc((void**)&r->h_frame, sizeof(MegaFrame)) != hipSuccess)
+            return bail(fail(RT_ERR_OOM, "frame constant buffer allocation failed"));
+    }
     if (kind == RT_RENDERER_WAVEFRONT) {
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
@@ -1155,6 +1222,8 @@ void rt_renderer_destroy(rt_renderer* r) {
         free_tile_buffers(r);
         if (r->d_cam) (void)hipFree(r->d_cam);
         if (r->h_cam) (void)hipHostFree(r->h_cam);
+        if (r->d_frame) (void)hipFree(r->d_frame);
+        if (r->h_frame) (void)hipHostFree(r->h_frame);
         for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
         if (r->ev_begin) (void)hipEventDestroy(r->ev_begin);
         if (r->ev_end) (void)hipEventDestroy(r->ev_end);
@@ -1211,7 +1280,11 @@ int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
     if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1 || s->fused_bounce > 1)
         return fail(RT_ERR_INVALID, "schedule field out of range");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
-    if (r->kind != RT_RENDERER_WAVEFRONT) return RT_OK; // the megakernel is one launch: nothing to schedule
+    if (s->pixel_slices < -1 || s->pixel_slices > (int32_t)kMaxSlices) return fail(RT_ERR_INVALID, "pixel_slices: -1 (automatic), 0 or 1 (off), 2 .. 8");
+    if (r->kind != RT_RENDERER_WAVEFRONT && s->pixel_slices == r->sched.pixel_slices) { // the megakernel is one launch: only its pixel slices are a choice
+        r->sched = *s;
+        return RT_OK;
+    }
     HIPCHK(hipSetDevice(r->scene->device));
     drain_streams(r, r->pending_stream); // the queues are re-allocated (stream lanes, second queue, hit records, dynamic queue)
     const rt_schedule old = r->sched;

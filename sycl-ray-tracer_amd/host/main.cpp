@@ -51,7 +51,7 @@ int main(int argc, const char* argv[]) {
     int device = 0, bvh = RT_BVH_DEFAULT;
     std::vector<int> devices;
     bool have_scene = false;
-    rt_schedule schedule{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u}; // the library's default
+    rt_schedule schedule{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u, -1}; // the library's default
     bool schedule_given = false;
 
     auto need = [&](int& i) -> const char* {

@@ -90,7 +90,7 @@ struct HipRendererBase : public IRenderer {
     uint32_t russian_roulette = 0;    // extension, 0 = off (rt_renderer_set_russian_roulette)
     // Extension: which of the wavefront renderer's schedules renders the frame (rt_renderer_set_schedule; same frame bit for bit). The
     // reference has one, a launch per bounce (src/render_wavefront.cpp:396-417): finish_depth = RT_SCHED_ALL_BOUNCES. Ignored by the megakernel.
-    rt_schedule schedule{};
+    rt_schedule schedule{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u, -1};
     bool has_schedule = false;
     // Extension: more than one entry tiles the frame over these HIP devices in THIS process, one host thread per
     // tile (interleaved 8-row strips, tile k -> devices[k]; the same device may appear more than once). Every tile is

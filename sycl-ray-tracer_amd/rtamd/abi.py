@@ -108,6 +108,7 @@ class rt_schedule(C.Structure):
         ("cost_order", C.c_int32),
         ("hip_graph", C.c_uint32),
         ("fused_bounce", C.c_uint32),
+        ("pixel_slices", C.c_int32),
     ]
 
 
@@ -126,7 +127,7 @@ class rt_stats(C.Structure):
         ("cost_ordered", C.c_uint32),
         ("kernel_ms", C.c_double * RT_K_COUNT),
         ("hw_queues", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("pixel_slices", C.c_uint32),
     ]
 
 

@@ -106,13 +106,14 @@ class Frame:
     cost_ordered: bool = False
     kernel_ms: dict = None       # with profiling: summed launch durations per kernel family (hipEvents on the launches' own streams)
     hw_queues: int = 0           # GPU_MAX_HW_QUEUES as the library read it (4 = HIP's default): bounds the automatic stream lanes
+    pixel_slices: int = 0        # megakernel: slices a pixel's samples were rendered in (1 = every pixel on one lane)
 
     @classmethod
     def from_stats(cls, f, b, st):
         return cls(f, b, int(st.rays), st.seconds, st.device_ms, st.hot_kernel_ms, int(st.hot_kernel_launches), int(st.launches),
                    {name: int(st.launches_by_kernel[i]) for name, i in abi.KERNELS.items()}, int(st.stream_lanes),
                    int(st.samples_per_launch), int(st.finish_depth), bool(st.cost_ordered),
-                   {name: float(st.kernel_ms[i]) for name, i in abi.KERNELS.items()}, int(st.hw_queues))
+                   {name: float(st.kernel_ms[i]) for name, i in abi.KERNELS.items()}, int(st.hw_queues), int(st.pixel_slices))
 
     def stat_lines(self) -> list[str]:
         """The three lines benchmark.py scrapes (src/render_wavefront.cpp:425-427, benchmark.py:49-55)."""
@@ -147,12 +148,12 @@ class IRenderer:
 
     def set_schedule(self, finish_depth: int = 0, samples_per_launch: int = 0, stream_lanes: int = 0, requeue: int = -1,
                      reorder: bool = False, matsort: bool = False, cost_order: int = -1, hip_graph: bool = False,
-                     fused_bounce: bool = False) -> None:
+                     fused_bounce: bool = False, pixel_slices: int = -1) -> None:
         """rt_renderer_set_schedule: which of the wavefront renderer's schedules renders the frame (same frame bit for bit; the
         reference has one: a launch per bounce, src/render_wavefront.cpp:396-417 = finish_depth=abi.RT_SCHED_ALL_BOUNCES).
-        Frame.kernels reports what ran. The megakernel ignores it."""
+        Frame.kernels reports what ran. The megakernel uses pixel_slices only (-1 automatic, 0 / 1 off, 2 .. 8: rt_mi355x.h)."""
         sc = abi.rt_schedule(int(finish_depth), int(samples_per_launch), int(stream_lanes), int(requeue), int(bool(reorder)),
-                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(bool(fused_bounce)))
+                             int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(bool(fused_bounce)), int(pixel_slices))
         abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)))
 
     def get_schedule(self) -> abi.rt_schedule:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(rtlib):
     for n in names:
         assert hasattr(rtlib, n), f"librt_mi355x.so does not export {n}"
         assert n in abi.PROTOTYPES, f"{n} has no ctypes prototype in rtamd/abi.py"
-    assert rtlib.rt_abi_version() == 7
+    assert rtlib.rt_abi_version() == 8
 
 
 def test_struct_layouts_match_header(tmp_path):
