@@ -168,17 +168,23 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
 // order are untouched: same RNG sequence, same additions in the same order, bit-identical frame.
 //   state : per pixel of the tile two 16-byte words {sum r, g, b, tag} {RNG word, tag, -, -}, each written with ONE write-through
 //           (sc1) store and read with an sc1 load: a word is seen whole, and a reader takes the state only if BOTH tags say "written
-//           for slice j of this frame" (tag0 + j; tag0 grows from frame to frame, the buffer is never cleared).
+//           for the slice of this frame that starts with sample s" (tag0 + s; tag0 grows by more than spp from frame to frame, the
+//           buffer is never cleared).
 //   order : slot q of the cursor = slice q / n_slots of pixel slot q % n_slots, so slice j of a pixel is handed out a whole sweep of the
-//           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it (rt_frame:
-//           mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) polls once per iteration of its
-//           wave's loop without holding the wave up. No lane ever waits for a LATER slot: nothing can deadlock.
+//           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it
+//           (mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) looks again in its wave's next
+//           shading round. No lane ever waits for a LATER slot: nothing can deadlock.
+//   cuts  : a lane knows its slice by the sample it starts with (taken from bound[] when the slot is claimed) and finds the slice's end
+//           in a 64-bit mask: bit k set = a slice ends before sample k << shift (shift = 0 up to 64 spp).
 constexpr uint32_t kMaxSlices = 8;
 struct SliceDev {
     u32x4* state;
-    uint32_t n_slices;        // 1: a lane keeps its pixel for all its samples
     uint32_t tag0;
-    uint32_t bound[kMaxSlices]; // slice j renders samples bound[j - 1] (0 for j = 0) ... bound[j] - 1; bound[n_slices - 1] = spp
+    uint32_t shift;
+    unsigned long long cuts;
+    uint32_t bound[kMaxSlices]; // slice j renders samples bound[j - 1] (0 for j = 0) ... bound[j] - 1; bound[n_slices - 1 ...] = spp
+    uint32_t n_slices;          // 1: a lane keeps its pixel for all its samples
+    uint32_t pad;
 };
 // The frame's constants that only a shading round or a refill reads — the camera's twelve floats, the slices — live in DEVICE memory and are
 // loaded where they are used (scalar loads, hot in the scalar cache): as kernel arguments hipcc kept them in ~35 scalar registers through the
@@ -190,7 +196,7 @@ struct MegaFrame {
     SliceDev sl;
 };
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, n_slices) == 8 && offsetof(SliceDev, bound) == 16, "frame_* below read MegaFrame by byte offset");
+static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, tag0) == 8 && offsetof(SliceDev, cuts) == 16 && offsetof(SliceDev, bound) == 24, "frame_* below read MegaFrame by byte offset");
 RT_DEV CameraDev frame_camera(const MegaFrame* f, int32_t width, int32_t height) { // the twelve floats as three scalar loads, here and now
     u32x4 a, b, c;
     asm volatile("s_load_dwordx4 %0, %3, 0x0\n\t"
@@ -208,18 +214,27 @@ RT_DEV CameraDev frame_camera(const MegaFrame* f, int32_t width, int32_t height)
     cam.width = width, cam.height = height;
     return cam;
 }
-struct SliceNow { // {state pointer, -, tag0} and the bounds, as loaded
-    u32x4 head;  // state lo, state hi, n_slices, tag0
-    u32x8 bound;
+struct SliceNow { // as loaded: {state pointer, tag0, shift}, cuts
+    u32x4 head;
+    u32x2 cuts;
 };
 RT_DEV SliceNow frame_slices(const MegaFrame* f) {
     SliceNow n;
     asm volatile("s_load_dwordx4 %0, %2, 0x38\n\t"
-                 "s_load_dwordx8 %1, %2, 0x48\n\t"
+                 "s_load_dwordx2 %1, %2, 0x48\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(n.head), "=&s"(n.bound)
+                 : "=&s"(n.head), "=&s"(n.cuts)
                  : "s"(f));
     return n;
+}
+RT_DEV uint32_t frame_slice_bound(const MegaFrame* f, uint32_t j) { // bound[j], j wave-uniform
+    uint32_t v;
+    const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x50u + 4u * j)); // (hipcc may keep a wave-uniform value in a vector register: "s" alone does not move it)
+    asm volatile("s_load_dword %0, %1, %2\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(v)
+                 : "s"(f), "s"(at));
+    return v;
 }
 template <bool STATS, bool SLICED>
 __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, const MegaFrame* frame, int32_t width, int32_t height, TileDev tile,
@@ -237,7 +252,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)(threadIdx.x & 63u);
     uint32_t* pixel_cursor = reinterpret_cast<uint32_t*>(ray_counter + 1);
-    int x = 0, ly = 0, gy = 0;
+    int x = 0, gy = 0;  // the lane's pixel: column, global row
+    uint32_t pix = 0;   // ... and its index in the tile (local row * width + x)
     uint32_t rng = 0, s = 0, depth = 0;
     unsigned long long wave_rays = 0; // rays traced by this wave (wave-uniform: a scalar pair, no lane register, no reduction at the end)
     // the pixel's colour sum lives in LDS (three planes, one slot per lane): touched once per PATH, it would otherwise hold three of the 80
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
     // A lane is `live` when it owns a pixel slice with samples left; `depth` then holds the bounces of its current path so far — or, in a
-    // SLICED launch, kPend | j: the lane has taken slice j > 0 of a pixel and waits for the state slice j - 1 ends with. It LOOKS for that
+    // SLICED launch, kPend: the lane has taken a later slice of a pixel (`s` = the sample it starts with) and waits for the state the slice before ends with. It LOOKS for that
     // state in every shading round of its wave, where a ray is started anyway (a waiting lane counts as one that waits for shading, so rounds
     // keep coming). A state poll of its own beside the refill, with its own copy of the camera-ray code and its own way round the wave's
     // loop, cost more registers than the kernel has: 51 spilled, 122 -> 145 ms.
@@ -267,20 +283,22 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     };
     // (ONE frame-wide cursor. Round 1 cut the frame into a region per XCD, for L2 locality: +4 % then, -2 % ... -16 % once the kernel was bound
     // by instruction issue — all waves should advance over one front, or the frame's last pixels all lie in the slowest region. EXPERIMENTS.md)
-    auto take_slot = [&](uint32_t p, uint32_t j) { // slice j of pixel slot p (8x8-tile order) becomes this lane's; slots outside the image are skipped
+    auto take_slot = [&](uint32_t p, uint32_t first) { // the slice of pixel slot p (8x8-tile order) that starts with sample `first` becomes this lane's; slots outside the image are skipped
         const uint32_t t = p >> 6; // (slots in row order instead of 8x8 blocks: +-0 on both scenes)
         x = (int)((t % tiles_x) * 8u + (p & 7u));
-        ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
+        const int ly = (int)((t / tiles_x) * 8u + ((p >> 3) & 7u));
         gy = tile_global_row(tile, ly);
+        pix = (uint32_t)ly * (uint32_t)width + (uint32_t)x;
         if (x < width && ly < tile.local_rows && gy < height) {
-            if (!SLICED || j == 0) {
+            s = first;
+            if (!SLICED || first == 0) {
                 rng = pixel_seed(x, gy, width, height, seed_mode);
                 *color_r = 0.0f, *color_g = 0.0f, *color_b = 0.0f;
-                s = 0, depth = 0;
+                depth = 0;
                 r = camera_ray(frame_camera(frame, width, height), x, gy, rng);
                 trav_begin(T, r.org, ray_dir(r), stack);
             } else {
-                depth = kPend | j;
+                depth = kPend; // the state the slice starts from comes from the lane that renders the slice before it (below)
             }
             live = true;
         }
@@ -310,14 +328,18 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(pixel_cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (SLICED)
+                uint32_t first_here = 0, first_next = 0; // first samples of the slice the claim starts in and of the one after it
+                if (SLICED) {
                     while (slice_j + 1u < n_slices && base >= (slice_j + 1u) * n_slots) slice_j++; // (the cursor only moves forward)
+                    if (slice_j) first_here = frame_slice_bound(frame, slice_j - 1u);
+                    first_next = frame_slice_bound(frame, slice_j);
+                }
                 const uint32_t slice_base = SLICED ? slice_j * n_slots : 0u, total_slots = SLICED ? n_slots * n_slices : n_slots;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                 const uint32_t q = base + rank;
                 if (!live && q < total_slots) {
                     const bool next = SLICED && q - slice_base >= n_slots; // a claim of at most 64 slots crosses at most one slice boundary
-                    take_slot(next ? q - slice_base - n_slots : q - slice_base, next ? slice_j + 1u : slice_j);
+                    take_slot(next ? q - slice_base - n_slots : q - slice_base, next ? first_next : first_here);
                 }
                 if (base + cnt >= total_slots) {
                     exhausted = true;
@@ -366,17 +388,12 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             if (SLICED && depth >= kPend) { // the state of the pixel: two 16-byte words, taken when both carry this slice's tag
                 const SliceNow sn = frame_slices(frame);
                 const auto rsrc = state_rsrc(sn);
-                const uint32_t j = depth & 0xFFu;
-                const uint32_t at = ((uint32_t)ly * (uint32_t)width + (uint32_t)x) * 32u, tag = sn.head.w + j;
+                const uint32_t at = pix * 32u, tag = sn.head.z + s;
                 const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
                 const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
                 if (w0.w == tag && w1.y == tag) {
                     *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.y), *color_b = __uint_as_float(w0.z);
                     rng = w1.x;
-                    s = sn.bound[0]; // (j >= 1: the slice starts with sample bound[j - 1])
-#pragma unroll
-                    for (uint32_t k = 1; k + 1u < kMaxSlices; ++k)
-                        if (j == k + 1u) s = sn.bound[k];
                     start = true;
                 }
             } else {
@@ -391,18 +408,18 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 if (done || killed || depth == max_depth) {
                     if (done) *color_r = *color_r + res.x, *color_g = *color_g + res.y, *color_b = *color_b + res.z; // paths that outlive max_depth add (0,0,0)
                     s++;
-                    uint32_t handed = 0; // the slice that starts with sample s, if this sample was the last of its slice
+                    bool handed = false; // this sample was the last of its slice: the pixel goes on in another lane
                     SliceNow sn{};
                     if (SLICED) {
                         sn = frame_slices(frame);
-#pragma unroll
-                        for (uint32_t k = 0; k + 1u < kMaxSlices; ++k) // (the bounds beyond the last slice repeat spp)
-                            if (s == sn.bound[k] && s < spp) handed = k + 1u;
+                        const unsigned long long cuts = ((unsigned long long)sn.cuts.y << 32) | sn.cuts.x;
+                        const uint32_t sh = sn.head.w;
+                        handed = s < spp && (s & ((1u << sh) - 1u)) == 0u && ((cuts >> (s >> sh)) & 1ull) != 0ull;
                     }
-                    if (SLICED && handed) { // the pixel goes on in another lane: its state, tagged for that slice
+                    if (SLICED && handed) { // its state, tagged with the sample the next slice starts with
                         live = false, pixel_finished = true;
                         const auto rsrc = state_rsrc(sn);
-                        const uint32_t at = ((uint32_t)ly * (uint32_t)width + (uint32_t)x) * 32u, tag = sn.head.w + handed;
+                        const uint32_t at = pix * 32u, tag = sn.head.z + s;
                         u32x4 w0, w1;
                         w0.x = __float_as_uint(*color_r), w0.y = __float_as_uint(*color_g), w0.z = __float_as_uint(*color_b), w0.w = tag;
                         w1.x = rng, w1.y = tag, w1.z = 0u, w1.w = 0u;
@@ -414,7 +431,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                         live = false, pixel_finished = true;
                         const float n = (float)spp;
                         const f3 c = mk3(__builtin_sqrtf(*color_r / n), __builtin_sqrtf(*color_g / n), __builtin_sqrtf(*color_b / n));
-                        const size_t o = ((size_t)ly * (size_t)width + (size_t)x);
+                        const uint32_t o = pix;
                         if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = make_float4(c.x, c.y, c.z, 1.0f);
                         if (out_u8)
                             reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |

@@ -499,23 +499,33 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
     const int32_t want = r->sched.pixel_slices;
     const double G = (double)n_slots / ((double)grid * kMegaBlock);
     if (!r->d_slice_state || want == 0 || want == 1 || r->spp < 2 || (want < 0 && G <= 1.25)) return sl;
+    // a slice ends at a multiple of 2^shift samples: the kernel finds the ends in a 64-bit mask, bit k = "a slice ends before sample k << shift"
+    uint32_t shift = 0;
+    while (((r->spp - 1u) >> shift) >= 64u) shift++;
+    const uint32_t unit = 1u << shift, units = (r->spp + unit - 1u) / unit; // the last unit may be a short one
+    if (units < 2) return sl;
     const double ratio = std::min(4.0, std::max(1.0, G / 1.5));
-    const double last = std::max(1.0, r->spp / 32.0);
-    uint32_t n = want >= 2 ? (uint32_t)want : (ratio > 1.05 ? 1u + (uint32_t)std::ceil(std::log(r->spp / last) / std::log(ratio)) : kMaxSlices);
-    n = std::min(std::min(n, kMaxSlices), r->spp);
+    const double last = std::max(1.0, units / 32.0);
+    uint32_t n = want >= 2 ? (uint32_t)want : (ratio > 1.05 ? 1u + (uint32_t)std::ceil(std::log(units / last) / std::log(ratio)) : kMaxSlices);
+    n = std::min(std::min(n, kMaxSlices), units);
     double wsum = 0.0;
     for (uint32_t i = 0; i < n; ++i) wsum += std::pow(ratio, (double)(n - 1 - i));
-    // sizes from the last slice up, each at least one sample; the first slice takes what is left
+    // sizes (in units) from the last slice up, each at least one unit; the first slice takes what is left
     std::vector<uint32_t> size(n, 1u);
     uint32_t used = 0;
     for (uint32_t i = n; i-- > 1;) {
-        size[i] = std::max<uint32_t>(1u, (uint32_t)std::lround(r->spp * std::pow(ratio, (double)(n - 1 - i)) / wsum));
-        size[i] = std::min(size[i], r->spp - used - i); // leave one sample for every earlier slice
+        size[i] = std::max<uint32_t>(1u, (uint32_t)std::lround(units * std::pow(ratio, (double)(n - 1 - i)) / wsum));
+        size[i] = std::min(size[i], units - used - i); // leave one unit for every earlier slice
         used += size[i];
     }
-    size[0] = r->spp - used;
+    size[0] = units - used;
     uint32_t b = 0;
-    for (uint32_t i = 0; i < n; ++i) b += size[i], sl.bound[i] = b;
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        b += size[i];
+        sl.bound[i] = b * unit; // (< spp: at least one unit follows)
+        sl.cuts |= 1ull << b;
+    }
+    sl.shift = shift;
     sl.n_slices = n;
     return sl;
 }
@@ -772,11 +782,12 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
-        if (r->slice_tag > 0xFFFFFF00u && r->d_slice_state) { // the tags are about to wrap (after 2^29 frames): start over from a cleared buffer
+        // tags of this frame: tag0 + (first sample of the slice the state is for), tag0 > every tag of the frames before
+        if (r->d_slice_state && r->slice_tag > 0xFFFFFFFFu - 2u * (r->spp + 1u)) { // about to wrap: start over from a cleared buffer
             HIPCHK(hipMemsetAsync(r->d_slice_state, 0, (size_t)r->n_local * 32, st));
             r->slice_tag = 0;
         }
-        r->slice_tag += kMaxSlices;
+        r->slice_tag += r->spp + 1u;
         const SliceDev sl = mega_slices(r, grid, tiles_x * tiles_y * 64u, r->slice_tag);
         if (stats) stats->pixel_slices = sl.n_slices;
         // (h_frame is rewritten per frame: the previous frame of this renderer has been collected, frame_begin refuses a second one in flight)

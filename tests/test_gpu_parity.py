@@ -1299,3 +1299,84 @@ def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypa
         _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"stats {cls.__name__} {sched}")
         r.close()
     assert "[rt stats]" in capfd.readouterr().err
+
+
+# ---- pixel slices of the megakernel (rt_schedule::pixel_slices) ------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,w,h,spp,depth", [("cornell", {}, 96, 64, 8, 6), ("atrium", {"detail": 1}, 120, 72, 5, 10), ("cube", {}, 97, 61, 3, 4)])
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_pixel_slices_keep_the_frame_where_every_slice_has_to_wait(gpu_scenes, oracle, scene_cache, name, kw, w, h, spp, depth, slices):
+    """A pixel's samples rendered as `slices` slices by different lanes (state through memory) instead of by one lane. On a tile this small
+    every lane of the machine is free when the cursor hands out slice j of a pixel, so slice j is taken while slice j - 1 is still being
+    rendered: the path where a lane WAITS for its pixel's state runs for every pixel. Same frame, same ray count, bit for bit; more slices
+    than samples are cut down to one sample per slice."""
+    sd = scene_cache(name, **kw)
+    gs = gpu_scenes(name, **kw)
+    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_MEGAKERNEL, depth, spp)
+    r = MegakernelRenderer(gs, (w, h), depth, spp)
+    r.set_schedule(pixel_slices=slices)
+    cam = Camera.for_scene(sd, (w, h))
+    for frame in range(3):  # the state buffer is never cleared: tags tell the frames apart
+        got = r.render_frame(cam)
+        assert got.pixel_slices == min(slices, spp)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} {slices} slices, frame {frame}")
+    r.set_schedule(pixel_slices=0)
+    got = r.render_frame(cam)
+    assert got.pixel_slices == 1
+    _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} unsliced")
+    r.close()
+
+
+@pytest.mark.gpu
+def test_pixel_slices_are_chosen_by_tile_size_and_keep_the_frame(gpu_scenes, oracle, scene_cache):
+    """Automatic slicing: none for a tile of at most ~1.25 pixels per resident lane (one generation of pixel chains: nothing is handed out
+    later), several for a frame of several generations — and the frame, the tile split and the STATS instantiation are the same bits."""
+    sd = scene_cache("atrium", detail=1)
+    gs = gpu_scenes("atrium", detail=1)
+    w, h, spp, depth = 1600, 904, 4, 10  # 1.45 M pixels on 393,216 lanes: 3.7 generations
+    cam = Camera.for_scene(sd, (w, h))
+    r = MegakernelRenderer(gs, (w, h), depth, spp)
+    auto = r.render_frame(cam)
+    assert auto.pixel_slices > 1
+    r.set_schedule(pixel_slices=0)
+    plain = r.render_frame(cam)
+    assert plain.pixel_slices == 1 and plain.rays == auto.rays
+    np.testing.assert_array_equal(auto.rgba_f32, plain.rgba_f32)
+    np.testing.assert_array_equal(auto.rgba_u8, plain.rgba_u8)
+    r.set_schedule(pixel_slices=-1)
+    r.set_tile(0, 8, 8)  # 0.46 generations: the chain regime
+    assert r.render_frame(cam).pixel_slices == 1
+    r.set_tile(1, 2, 8)
+    half = r.render_frame(cam)
+    assert half.pixel_slices > 1
+    np.testing.assert_array_equal(half.rgba_f32, plain.rgba_f32[r.global_rows()])
+    r.close()
+    # strips of the sliced frame against the oracle
+    _assert_strips_equal_the_oracle(oracle, sd, abi.RT_RENDERER_MEGAKERNEL, w, h, depth, spp, [("automatic slices", auto.rgba_f32, auto.rgba_u8)], (0, 56, 112),
+                                    what="atrium 1600x904 sliced")
+
+
+@pytest.mark.gpu
+def test_pixel_slices_in_the_instrumented_kernel_and_with_roulette(gpu_scenes, oracle, scene_cache, monkeypatch):
+    sd = scene_cache("cornell")
+    gs = gpu_scenes("cornell")
+    w, h, spp, depth = 96, 64, 6, 8
+    cam = Camera.for_scene(sd, (w, h))
+    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_MEGAKERNEL, depth, spp)
+    monkeypatch.setenv("RT_KERNEL_STATS", "1")
+    r = MegakernelRenderer(gs, (w, h), depth, spp)
+    r.set_schedule(pixel_slices=4)
+    got = r.render_frame(cam)
+    assert got.pixel_slices == 4
+    _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, "STATS instantiation, 4 slices")
+    r.close()
+    monkeypatch.delenv("RT_KERNEL_STATS")
+    osc = oracle.OracleScene(sd)
+    ocam = oracle.camera(w, h, sd.camera.position, sd.camera.direction, sd.camera.focal_length)
+    f, b, rays = osc.render(ocam, abi.RT_RENDERER_MEGAKERNEL, depth, spp, use_bvh=False, rr_start=2)
+    r = MegakernelRenderer(gs, (w, h), depth, spp)
+    r.set_russian_roulette(2)
+    r.set_schedule(pixel_slices=3)
+    got = r.render_frame(cam)
+    _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, "roulette, 3 slices")
+    r.close()
