@@ -489,7 +489,7 @@ int alloc_tile_buffers(rt_renderer* r) {
 // Pixel slices of a megakernel frame (rt_kernels.h: SliceDev). G = pixel slots per resident lane, the frame's "generations". Slice j + 1 of a
 // pixel is handed out one sweep of the cursor after slice j, and a sweep over slices of length f takes G x f: the next slice is ready as long
 // as slices shrink by less than G from one to the next — by G / 1.5 here, at most 4, for the spread of the pixels' costs. The frame drains
-// over its LAST slice (1/32 of the samples where the slice count allows), instead of over a whole pixel.
+// over its LAST slice (about 1/16 of the samples), instead of over a whole pixel.
 //   G <= 1.25 : one slice — nothing is handed out after the first generation, a slice would only wait for the one before it
 //   forced    : rt_schedule::pixel_slices >= 2 slices of that geometry whatever G is (tests, sweeps)
 SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint32_t tag0) {
@@ -505,8 +505,12 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
     const uint32_t unit = 1u << shift, units = (r->spp + unit - 1u) / unit; // the last unit may be a short one
     if (units < 2) return sl;
     const double ratio = std::min(4.0, std::max(1.0, G / 1.5));
-    const double last = std::max(1.0, units / 32.0);
-    uint32_t n = want >= 2 ? (uint32_t)want : (ratio > 1.05 ? 1u + (uint32_t)std::ceil(std::log(units / last) / std::log(ratio)) : kMaxSlices);
+    // (measured, atrium 1080p 64 spp, profiles/r05_slice_sweep.txt: slices from 48, 60 on 111.7 ms, from 46, 59, 63 on 112.7, from 56 on 114.9, unsliced
+    // 119.9; half the frame: from 32, 48, 56, 60 on 57.4 ms, unsliced 67.0; a quarter: eight equal slices 32.7 ms, unsliced 42.5 — a last slice
+    // of 1/16 of the samples is short enough, shorter ones only add hand-overs)
+    const double last = std::max(1.0, units / 16.0);
+    uint32_t n = want >= 2 ? (uint32_t)want : (ratio > 1.05 ? 1u + (uint32_t)std::floor(std::log(units / last) / std::log(ratio) + 1e-9) : kMaxSlices);
+    n = std::max(n, 2u);
     n = std::min(std::min(n, kMaxSlices), units);
     double wsum = 0.0;
     for (uint32_t i = 0; i < n; ++i) wsum += std::pow(ratio, (double)(n - 1 - i));
@@ -527,6 +531,19 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
     }
     sl.shift = shift;
     sl.n_slices = n;
+#ifdef RT_DEVELOPER_KNOBS
+    if (const char* e = std::getenv("RT_MEGA_SLICE_BOUNDS")) { // sweeps: the samples slices 1, 2, ... start with, ascending, e.g. "48,60,63" (shift 0 only)
+        sl.cuts = 0, sl.n_slices = 1;
+        for (uint32_t k = 0; k < kMaxSlices; ++k) sl.bound[k] = r->spp;
+        uint32_t prev = 0;
+        for (const char* p = e; *p && sl.n_slices < kMaxSlices && shift == 0;) {
+            const uint32_t v = (uint32_t)std::strtoul(p, const_cast<char**>(&p), 10);
+            if (*p == ',') ++p;
+            if (v <= prev || v >= r->spp) break;
+            sl.bound[sl.n_slices - 1] = v, sl.cuts |= 1ull << v, sl.n_slices++, prev = v;
+        }
+    }
+#endif
     return sl;
 }
 
