@@ -19,16 +19,18 @@ Four renderers of the path are measured with the same K steps:
   wavefront_per_bounce_fused  the same with ONE kernel per bounce (intersect + shade + compact: the reference's shoot_rays, :222-312)
 The headline `value` is the fastest (`config.renderer`); `renderers` holds all four with their rooflines.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel of the headline renderer: algorithmic bytes / measured launch time vs the 8 TB/s HBM peak (the
-                 contractual figure: tiny by construction for a traversal kernel), `traffic` = FETCH_SIZE + WRITE_SIZE of that
-                 kernel, and `binding` = the bound that actually binds, MEASURED: VALU issue busy = 4 x (SQ_ACTIVE_INST_VALU -
-                 SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel cycles) — counters of the product build in this very run, no model
-                 (semantics pinned on known instruction streams: profiles/r03_valu_calibration2.json). traffic and binding are
-                 measured at N = 1: after the timed region one more frame per renderer is rendered in a child process under
-                 `rocprofv3 --pmc`, one pass per counter group (counters only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     — of the headline renderer, as SURVEY §8(d) states it: algorithmic bytes per unit of work x units per second of the whole timed
+                 region against the 8 TB/s HBM peak (tiny by construction for a traversal kernel), the dominant kernel's own per-launch
+                 figure under `per_launch`; `traffic` = FETCH_SIZE + WRITE_SIZE of that kernel; `binding` = the bounds that actually bind,
+                 MEASURED: VALU issue busy = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel cycles) and the vector L1's
+                 tag look-ups per cycle and CU — counters of the product build in this very run, no model (semantics pinned on known
+                 instruction streams: profiles/r03_valu_calibration2.json). traffic and binding are measured at N = 1: after the timed
+                 region one more frame per renderer is rendered in a child process under `rocprofv3 --pmc`, one pass per counter group.
   cpu_baseline — the CPU oracle (a port, not the reference: the reference cannot be built here) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  workload_sensitivity — information only (N = 1): the megakernel with the same K frames on the atrium turned out of the coordinate axes and on the
+                 voxel terrain, each with node visits / triangle tests per ray: the bench scene is this traversal's best case.
 For N > 1 the line also carries `per_rank_ms` (every rank's own time for the K frames), `gather_ms` (rank 0's mean time in the
 gather + de-interleave per frame) and `rccl_ranks` (an all-reduce of ones over the process group: what RCCL saw).
 
@@ -66,11 +68,20 @@ SHOOT_BYTES_PER_RAY = 76
 # and consumed by k_wf_finish, which follows every path to its end in registers:
 #   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
 FINISH_BYTES_PER_PATH = 74
-MEGAKERNEL_BYTES_PER_PIXEL = 16  # one fp32 RGBA store per pixel per frame (the timed region stores no RGBA8 image)
-# SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 40-B triangle records, 124 B of hit shading;
-# per-ray counts of the atrium measured with RT_KERNEL_STATS=1 (profiles/r04_wave_stats.txt): 17.28 nodes, 2.36 triangles
-TRAVERSAL_BYTES_PER_RAY = 17.28 * 64 + 2.36 * 40 + 124
+# the megakernel's HBM stream is its output — one fp32 RGBA store (16 B) and, as the reference's K1 writes it too
+# (src/render_megakernel.cpp:154-158), one RGBA8 store (4 B) per pixel and frame — plus, since round 5, the pixel state that changes lanes
+# between two slices of a pixel's samples (rt_kernels.h: SliceDev): 32 B written + 32 B read per hand-over.
+MEGAKERNEL_BYTES_PER_PIXEL = 20
+SLICE_HANDOVER_BYTES = 64
+# SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 40-B triangle records, 124 B of hit shading; per-ray counts of the
+# atrium from the kernel's own counters (RT_KERNEL_STATS=1; re-measured in every run by the workload_sensitivity leg): 17.28 node visits,
+# 9.28 of them in the LDS-staged top of the tree, 2.36 triangle tests
+ATRIUM_VISITS = {"node_visits_per_ray": 17.28, "node_visits_in_lds_per_ray": 9.28, "triangle_tests_per_ray": 2.36}
+NODE_BYTES, TRI_BYTES, HIT_SHADING_BYTES = 64, 40, 124
+LDS_PEAK_GBS = 150000.0          # MI355X_MICROARCH.md (LDS): ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md (L2): ~34.5 TB/s aggregate
 N_SIMDS = 1024                   # 256 CUs x 4
+N_CUS = 256
 RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce", "wavefront_per_bounce_fused")
 
 
@@ -94,6 +105,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-frames-in-flight measurement")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes after the timed region")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the information-only workload_sensitivity leg (the megakernel on the rotated atrium and the voxel terrain)")
+    ap.add_argument("--stats-child", default=None, help=argparse.SUPPRESS)  # comma-separated scenes: one 4-spp frame each under RT_KERNEL_STATS=1 (node visits / triangle tests per ray)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: CPU rehearsal of the multi-rank path (needs --rehearsal-tiles)")
     ap.add_argument("--rehearsal-tiles", default=None, help="directory with tile_<rank>.npy (rows x W x 4 float32): used INSTEAD of rendering")
     ap.add_argument("--dump-frame", default=None, help="rank 0 writes the last gathered frame here (.npy)")
@@ -131,7 +144,7 @@ def main() -> int:
     # libraries may say more. File descriptor 1 is pointed at stderr for the life of the process; emit() writes to the saved one.
     global _JSON_FD
     launcher = "WORLD_SIZE" not in os.environ and args.gpus > 1  # (the launcher's child ranks do this themselves)
-    if _JSON_FD is None and not args.pmc_child and not launcher:
+    if _JSON_FD is None and not args.pmc_child and not args.stats_child and not launcher:
         sys.stdout.flush()
         _JSON_FD = os.dup(1)
         os.dup2(2, 1)
@@ -140,6 +153,8 @@ def main() -> int:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         return pmc_child(args)
+    if args.stats_child:
+        return stats_child(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)  # before any torch / HIP call in this process
 
@@ -261,6 +276,7 @@ def main() -> int:
                 tot["hot_launches"] += fr.hot_kernel_launches
                 tot["dev_ms"] += fr.device_ms
                 tot["lanes"] = fr.stream_lanes
+                tot["pixel_slices"] = fr.pixel_slices
                 for kn, v in fr.kernel_ms.items():
                     tot["kernel_ms"][kn] = tot["kernel_ms"].get(kn, 0.0) + v
                 for kn, v in fr.kernels.items():
@@ -368,6 +384,15 @@ def main() -> int:
                                            "ms_per_step": pipelined["ms_per_step"],
                                            "note": "same K frames with the next frame enqueued (second renderer + strip buffer) before the "
                                                    "current one is collected; not the headline: ms_per_step is then no longer one frame's latency"}
+        if world == 1 and not rehearsal and not args.no_sensitivity and "megakernel" in out["renderers"]:
+            try:
+                out["workload_sensitivity"] = workload_sensitivity(args, out["renderers"]["megakernel"]["value"], abi, Scene, Camera, MegakernelRenderer)
+                mine = out["workload_sensitivity"]["scenes"].get("atrium", {})
+                if "node_visits_per_ray" in mine:  # this run's counters instead of the constants
+                    mk = out["renderers"]["megakernel"]
+                    mk["roofline"]["traversal"] = traversal_object({k: mine[k] for k in ATRIUM_VISITS}, mk["value"] * 1e6, "measured in this run (RT_KERNEL_STATS=1 child, 4 spp)")
+            except Exception as e:  # information only: never the reason a bench line is missing
+                out["workload_sensitivity"] = {"error": str(e)[:300]}
         if world == 1 and not rehearsal:
             attach_pmc(out, args)
         if world == 1 and not rehearsal and not args.no_cpu_baseline:
@@ -407,32 +432,46 @@ def shared_scene(args, rank, world, use_dist):
 
 
 def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
-    """The contractual roofline object of one renderer on THIS rank: algorithmic bytes per launch of its dominant kernel / that
-    kernel's mean launch duration (hipEvents on the launch's own stream) against the HBM peak."""
+    """The roofline object of one renderer on THIS rank, as SURVEY §8(d) states it: algorithmic bytes per unit of work x units per second
+    over the WHOLE timed region (wall clock: every launch, tail and gap included) against the HBM peak —
+        wavefront renderers: rays/s x bytes per ray (76 B fused per-bounce kernel; 40 + 92 B EXTEND + SHADE; 74 B per PATH for the one-launch schedule)
+        megakernel         : pixels/s x (20 B + 64 B per slice hand-over)
+    `per_launch` keeps the dominant kernel's own figure (its bytes / its mean launch duration from hipEvents on the launch's stream: what
+    `rocprofv3 --kernel-trace --stats` reports for that kernel); where stream lanes overlap, launch durations overlap too, which is why that
+    figure is not the frame's."""
     hot_launches, hot_ms = tot["hot_launches"], tot["hot_ms"]
     rays = tot.get("profiled_rays", tot["rays"])  # rays of the frames the kernel durations were taken over
+    pixels = rows * W
     if name == "wavefront":
-        kernel, bytes_per_launch = "k_wf_finish<false, false, false>", FINISH_BYTES_PER_PATH * (rows * W * args.spp * args.steps) / max(hot_launches, 1)
+        kernel, unit, units_per_s, bytes_per_unit = "k_wf_finish<false, false, false>", "path", pixels * args.spp * args.steps / elapsed, FINISH_BYTES_PER_PATH
+        bytes_per_launch = FINISH_BYTES_PER_PATH * (pixels * args.spp * args.steps) / max(hot_launches, 1)
     elif name == "wavefront_per_bounce":
-        kernel, bytes_per_launch = "k_wf_extend", EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
+        kernel, unit, units_per_s, bytes_per_unit = "k_wf_extend", "ray", rays_all / elapsed, EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
+        bytes_per_launch = EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
     elif name == "wavefront_per_bounce_fused":
-        kernel, bytes_per_launch = "k_wf_finish<false, false, true>", SHOOT_BYTES_PER_RAY * rays / max(hot_launches, 1)
+        kernel, unit, units_per_s, bytes_per_unit = "k_wf_finish<false, false, true>", "ray", rays_all / elapsed, SHOOT_BYTES_PER_RAY
+        bytes_per_launch = SHOOT_BYTES_PER_RAY * rays / max(hot_launches, 1)
     else:
-        kernel, bytes_per_launch = "k_megakernel", MEGAKERNEL_BYTES_PER_PIXEL * rows * W
+        slices = max(int(tot.get("pixel_slices", 1)), 1)
+        kernel, unit, units_per_s = "k_megakernel", "pixel", pixels * args.steps / elapsed
+        bytes_per_unit = MEGAKERNEL_BYTES_PER_PIXEL + SLICE_HANDOVER_BYTES * (slices - 1)
+        bytes_per_launch = bytes_per_unit * pixels
     mean_launch_s = (hot_ms / max(hot_launches, 1)) * 1e-3
-    achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+    per_launch = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+    achieved = units_per_s * bytes_per_unit / 1e9
     roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": hot_launches,
-            "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1)}
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "formula": f"{unit}s per second of the timed region x {bytes_per_unit} B per {unit} (SURVEY.md 8d) / {HBM_PEAK_GBS:.0f} GB/s",
+            "bytes_per_" + unit: bytes_per_unit, unit + "s_per_s": round(units_per_s, 1),
+            "per_launch": {"achieved": round(per_launch, 3), "frac": round(per_launch / HBM_PEAK_GBS, 6), "launches": hot_launches,
+                           "mean_launch_ms": round(mean_launch_s * 1e3, 5), "bytes_per_launch": round(bytes_per_launch, 1),
+                           "note": "the dominant kernel alone: its algorithmic bytes per launch / its mean launch duration (hipEvents on the launch's own stream)"}}
     if name == "wavefront_per_bounce":
-        # both kernels of the pipeline, each against its own algorithmic bytes; the launches of the two stream lanes overlap, so the
+        # both kernels of the pipeline, each against its own algorithmic bytes; the launches of the stream lanes overlap, so the
         # per-kernel sums are device time of a lane, not wall time
         ext_s, shd_s = tot["kernel_ms"].get("wf_extend", 0.0) * 1e-3, tot["kernel_ms"].get("wf_shade", 0.0) * 1e-3
         n_pairs = max(tot["kernels"].get("wf_shade", 0) // max(args.steps, 1) * kernel_frames, 1)
         roof["pipeline"] = {
-            "bytes_per_ray": EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY,
-            "achieved_gbs_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9, 3),
-            "frac_whole_frame": round((EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY) * rays_all / elapsed / 1e9 / HBM_PEAK_GBS, 6),
             "k_wf_extend": {"bytes_per_ray": EXTEND_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(ext_s * 1e3 / kernel_frames, 3),
                             "achieved_gbs": round(EXTEND_BYTES_PER_RAY * rays / ext_s / 1e9, 3) if ext_s else None},
             "k_wf_shade": {"bytes_per_ray": SHADE_BYTES_PER_RAY, "sum_launch_ms_per_frame": round(shd_s * 1e3 / kernel_frames, 3),
@@ -442,21 +481,31 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
             "stream_lanes": tot["lanes"], "launch_pairs_per_frame": n_pairs // kernel_frames,
             "kernel_durations_from": "one frame with per-launch hipEvents rendered after the timed region (events on ~3,800 launches slow the timed frames by a third)",
             "note": "the reference's shape: per sample and bounce one EXTEND + one SHADE launch, survivors compacted between bounces (wave ballot + mbcnt "
-                    "prefix, one atomic per 256-thread block); two interleaved sub-tiles on two HIP streams overlap one lane's launch tails with the other's traversal"}
+                    "prefix, one atomic per 256-thread block); interleaved sub-tiles on HIP streams overlap one lane's launch tails with the others' traversal"}
     elif name == "wavefront_per_bounce_fused":
-        roof["bytes_per_ray"] = SHOOT_BYTES_PER_RAY
         roof["stream_lanes"] = tot["lanes"]
         roof["schedule"] = ("one launch per sample and bounce of k_wf_finish limited to one bounce (SHOOT): intersect, shade, survivors compacted into the next queue — wave "
                             "ballot + mbcnt ranks, slots from a per-workgroup block (one device atomic per 256 rays)")
     elif name == "wavefront":
-        roof["bytes_per_path"] = FINISH_BYTES_PER_PATH
         roof["schedule"] = "one k_wf_generate + one k_wf_finish launch per frame (rt_schedule default: DESIGN.md §5)"
     else:
-        roof["traversal_bytes_per_ray"] = round(TRAVERSAL_BYTES_PER_RAY, 1)  # gathers, served by LDS / L1 / L2 / Infinity Cache
-        roof["traversal_achieved_gbs"] = round(TRAVERSAL_BYTES_PER_RAY * rays_all / elapsed / 1e9, 1)
-    roof["note"] = ("a traversal kernel's algorithmic HBM traffic is its ray-state / frame stream only (SURVEY.md §8d); its real work is gathers from the "
-                    "cache-resident scene and instruction issue: see `binding` (measured VALU issue busy) and `traffic`")
+        roof["pixel_slices"] = max(int(tot.get("pixel_slices", 1)), 1)
+        roof["traversal"] = traversal_object(ATRIUM_VISITS, rays_all / elapsed, "constants of bench.py (profiles/r04_wave_stats.txt); replaced by this run's counters when the workload_sensitivity leg ran")
+    roof["note"] = ("a traversal kernel's algorithmic HBM traffic is its ray-state / frame stream only (SURVEY.md §8d): the fraction is tiny by construction. Its work is "
+                    "gathers from the cache-resident scene and instruction issue: see `binding` (measured VALU issue busy and vector-L1 tag look-ups) and `traffic`")
     return roof
+
+
+def traversal_object(visits, rays_per_s, source):
+    """SURVEY §8d's 'traversal bytes per ray' split by who serves them: node visits in the LDS-staged top of the tree against the LDS peak,
+    everything else (nodes below the top, triangle records, hit shading) through the vector L1 / L2 against the L2 peak."""
+    lds = visits["node_visits_in_lds_per_ray"] * NODE_BYTES
+    cached = (visits["node_visits_per_ray"] - visits["node_visits_in_lds_per_ray"]) * NODE_BYTES + visits["triangle_tests_per_ray"] * TRI_BYTES + HIT_SHADING_BYTES
+    return {"bytes_per_ray": round(lds + cached, 1), "from_lds_bytes_per_ray": round(lds, 1), "through_l1_l2_bytes_per_ray": round(cached, 1),
+            "from_lds_gbs": round(lds * rays_per_s / 1e9, 1), "lds_peak_gbs": LDS_PEAK_GBS, "from_lds_frac": round(lds * rays_per_s / 1e9 / LDS_PEAK_GBS, 4),
+            "through_l1_l2_gbs": round(cached * rays_per_s / 1e9, 1), "l2_peak_gbs": L2_PEAK_GBS, "through_l1_l2_frac": round(cached * rays_per_s / 1e9 / L2_PEAK_GBS, 4),
+            "visits": visits, "visits_source": source,
+            "note": "64-B nodes, 40-B triangle records, 124 B of hit shading per ray; peaks: MI355X_MICROARCH.md (LDS ~150 TB/s aggregate, L2 ~34.5 TB/s aggregate)"}
 
 
 # ---- live counters ------------------------------------------------------------------------------------------------------------------
@@ -481,11 +530,99 @@ def pmc_child(args):
     return 0
 
 
+SENSITIVITY_SCENES = ("atrium", "atrium_rotated", "atrium_tilted", "voxel_terrain")
+
+
+def sensitivity_scene(name, detail):
+    from rtamd import scenes
+    if name == "atrium":
+        return scenes.atrium_scene(detail)
+    if name == "atrium_rotated":   # the bench scene's own triangles, turned 33 degrees about (0.3, 1, 0.2): nothing is axis-aligned any more
+        return scenes.atrium_tilted_scene(detail, coarse=False)
+    if name == "atrium_tilted":    # ... with walls, floor, slabs and roof as TWO triangles each (how a modelling tool exports them; the real Sponza's large polygons)
+        return scenes.atrium_tilted_scene(detail, coarse=True)
+    return scenes.voxel_scene(detail)  # the reference's second workload class (benchmark.py:18 minecraft.glb): axis-aligned unit faces, open sky
+
+
+def stats_child(args):
+    """One 4-spp frame per listed scene with the megakernel under RT_KERNEL_STATS=1 (the STATS instantiation's own counters go to stderr, the
+    parent parses them): node visits and triangle tests per ray do not depend on the sample count."""
+    from rtamd import abi
+    from rtamd.renderer import Camera, MegakernelRenderer, Scene
+    for name in args.stats_child.split(","):
+        sd = sensitivity_scene(name, args.detail)
+        scene = Scene(sd, device=0, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+        r = MegakernelRenderer(scene, (args.width, args.height), args.depth, 4)
+        sys.stderr.write(f"[stats child] scene {name}\n"); sys.stderr.flush()
+        r.render_frame(Camera.for_scene(sd, (args.width, args.height)), want_f32=False, want_u8=False)
+        r.close(); scene.close()
+    return 0
+
+
+def visits_per_ray(args, names):
+    """{scene: {node_visits_per_ray, node_visits_in_lds_per_ray, triangle_tests_per_ray}} from the kernel's own counters, or {} when the child fails."""
+    import re
+    child = [sys.executable, str(REPO / "bench.py"), "--stats-child", ",".join(names), "--width", str(args.width), "--height", str(args.height),
+             "--depth", str(args.depth), "--detail", str(args.detail), "--bvh", args.bvh]
+    env = dict(os.environ, RT_KERNEL_STATS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(child, env=env, capture_output=True, text=True, timeout=300)
+    except Exception:
+        return {}
+    out, cur = {}, None
+    for line in p.stderr.splitlines():
+        m = re.match(r"\[stats child\] scene (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"per ray: ([0-9.]+) inner \(([0-9.]+) in the top \d+ nodes\), ([0-9.]+) tri", line)
+        if m and cur:
+            out[cur] = {"node_visits_per_ray": float(m.group(1)), "node_visits_in_lds_per_ray": float(m.group(2)), "triangle_tests_per_ray": float(m.group(3))}
+    return out
+
+
+def workload_sensitivity(args, headline_value, abi, Scene, Camera, MegakernelRenderer):
+    """Information only: how much of the headline is the SCENE. The generated atrium is an axis-aligned stand-in for Sponza — every large surface lies
+    in a coordinate plane, the best case for axis-aligned bounding boxes quantised on a per-node grid. The same K frames with the megakernel on the
+    same triangles turned out of the axes, on the two-triangle-wall variant, and on the reference's second workload class, each with the
+    kernel's own per-ray counters."""
+    W, H = args.width, args.height
+    out = {"note": "the bench scene is the BEST case of this traversal (axis-aligned surfaces): the rotated rows are the same renderer on geometry that is not; "
+                   "same resolution, spp, depth, warm-up and step count as the headline, one GPU", "renderer": "megakernel", "scenes": {}}
+    visits = visits_per_ray(args, SENSITIVITY_SCENES)
+    for name in SENSITIVITY_SCENES:
+        entry = {}
+        if name == "atrium":
+            entry = {"value": headline_value, "unit": "Mrays/s", "note": "the headline configuration (megakernel row of `renderers`)"}
+        else:
+            sd = sensitivity_scene(name, args.detail)
+            scene = Scene(sd, device=0, bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_LBVH)
+            cam = Camera.for_scene(sd, (W, H))
+            r = MegakernelRenderer(scene, (W, H), args.depth, args.spp)
+            for _ in range(args.warmup):
+                r.render_frame(cam, want_f32=False, want_u8=False)
+            import torch
+            torch.cuda.synchronize()
+            t0, rays = time.perf_counter(), 0
+            for _ in range(args.steps):
+                rays += r.render_frame(cam, want_f32=False, want_u8=False).rays
+            dt = time.perf_counter() - t0
+            entry = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt / args.steps * 1e3, 3), "triangles": int(sd.n_triangles),
+                     "rays_per_path": round(rays / args.steps / (W * H * args.spp), 3), "relative_to_headline_scene": round(rays / dt / 1e6 / headline_value, 3)}
+            r.close(); scene.close()
+        if name in visits:
+            entry.update(visits[name])
+        out["scenes"][name] = entry
+    return out
+
+
 # one rocprofv3 pass per group (counters only, no trace domains)
 PMC_PASSES = (("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_MISS_sum"),
               ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE"),
               ("SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_TRANS_F32"),
-              ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_SALU"))
+              ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_SALU"),
+              ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"))
 KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": ("k_wf_finish<false, false, false>",), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade"),
               "wavefront_per_bounce_fused": ("k_wf_finish<false, false, true>",)}
 
@@ -550,6 +687,12 @@ def binding_of(c, rays):
         b["instruction_mix"] = {t.lower(): round(v / n, 4) for t, v in typed.items()}
         b["instruction_mix"]["other (cmp, cndmask, min/max, mov, logic, shifts)"] = round(1.0 - sum(typed.values()) / n, 4)
         b["salu_per_valu"] = round(c.get("SQ_INSTS_SALU", 0.0) / n, 3)
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        # the SECOND loaded resource (round 4): a CU's vector L1 looks up one tag per cycle; a lane's 16-byte load is one look-up
+        acc = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        b["vector_l1"] = {"tag_lookups_per_cycle_and_cu": round(acc / (N_CUS * cycles), 4), "peak_per_cycle_and_cu": 1.0, "lookups_per_ray": round(acc / max(rays, 1), 1),
+                          "tag_conflict_stall_share_of_cycles": round(c.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0) / (N_CUS * cycles), 4),
+                          "measured": "TCP_TOTAL_CACHE_ACCESSES_sum / (256 CUs x GRBM_GUI_ACTIVE / 8)"}
     b["note"] = ("frac = share of the kernel's cycles in which a SIMD's vector ALU issued an instruction (all SIMDs, whole launch, drain tail included): measured, "
                  "no instruction-cost model. The rest is cycles with no VALU issue (waits on LDS / memory / scalar code in all resident waves).")
     return b
@@ -571,10 +714,10 @@ def attach_pmc(out, args):
         except Exception as e:  # no rocprofv3 / no counter access here: say so and use the committed profile of the same command
             source = f"live rocprofv3 --pmc unavailable ({str(e)[:160]}); "
     if c is None:
-        prof = REPO / "profiles" / "r04_pmc_bench.json"
+        prof = REPO / "profiles" / "r05_pmc_bench.json"
         if prof.exists():
             c = {k: v for k, v in json.loads(prof.read_text()).items() if isinstance(v, dict)}
-            source = (source or "") + "committed profiles/r04_pmc_bench.json (same command: scripts/final_profile.sh)"
+            source = (source or "") + "committed profiles/r05_pmc_bench.json (same command: scripts/final_profile.sh)"
     for name in want:
         roof = out["renderers"][name]["roofline"]
         rays = out["renderers"][name]["rays_per_frame"]

@@ -210,8 +210,10 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
  *   samples_per_launch  samples of a pixel one k_wf_finish launch renders. 0 = all of them: ONE launch per frame (default).
  *   stream_lanes        interleaved sub-tiles rendered on HIP streams of their own. 0 = automatic (1 for the one-launch
  *                       schedule, 3 for a launch or launch pair per bounce all the way down, 2 otherwise). HIP serves streams from
- *                       GPU_MAX_HW_QUEUES hardware queues (default 4): the library sets that variable to 8 when it is loaded unless
- *                       it is set already; a host that initialises HIP before loading the library should set it itself.
+ *                       GPU_MAX_HW_QUEUES hardware queues (default 4). The library never changes the environment: the HOST sets the
+ *                       variable (8) before its first HIP call; the library reads it once, when the process's first renderer is
+ *                       created, and resolves an automatic lane count down to lanes + 2 <= queues (rt_stats.hw_queues / .stream_lanes).
+ *                       Renderers of one device share their lane streams: drive them from one host thread.
  *   requeue             with samples_per_launch > 1: 1 = a pixel between two samples goes through a device-wide dynamic queue
  *                       (breadth first), 0 = it stays in its lane (depth first), -1 = automatic.
  *   reorder, matsort    SURVEY 8(f) row f-3, per-bounce schedule only: k_wf_shade bins a block's survivors by direction octant
@@ -230,8 +232,10 @@ int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce);
  *                       drains over its last, short slices instead of over whole pixels (bit-identical frame). -1 = automatic (as many
  *                       as the tile's size calls for; one for a tile of at most ~1.25 pixels per resident lane), 0 or 1 = off,
  *                       2 .. 8 = that many. rt_stats.pixel_slices reports what ran.
- * The environment variables RT_WF_FINISH_DEPTH / _SAMPLES_PER_LAUNCH / _STREAMS / _REQUEUE / _REORDER / _MATSORT / _LPT /
- * _GRAPH still work: rt_renderer_create turns them into the initial rt_schedule (a shim for scripts; tests use the API). */
+ * Environment: the library reads GPU_MAX_HW_QUEUES (above), RT_PROFILE_KERNELS=1 (rt_renderer_set_profiling at creation) and
+ * RT_KERNEL_STATS=1 (the instrumented kernel instantiations; their report goes to stderr) — and nothing else. Sweep knobs and test
+ * hooks (RT_WF_*, RT_MEGA_*, RT_BVH_*, RT_INJECT_ALLOC_FAILURE) exist in the developer build only: `make -C csrc dev` ->
+ * librt_mi355x_dev.so (csrc/rt_knobs.h). */
 #define RT_SCHED_ALL_BOUNCES 0xFFFFFFFFu
 typedef struct rt_schedule {
     uint32_t finish_depth;

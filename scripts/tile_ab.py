@@ -17,6 +17,8 @@ variants = []
 for a in sys.argv[3:]:
     label, _, envs = a.partition(":")
     variants.append((label, dict(e.split("=") for e in envs.split(",") if e)))
+if any(env for _, env in variants):  # knobs exist in the developer build only (csrc/rt_knobs.h)
+    os.environ.setdefault("RT_MI355X_LIB", str(REPO / "sycl-ray-tracer_amd" / "csrc" / "build" / "librt_mi355x_dev.so"))
 spp = int(os.environ.get("SPP", "64"))
 W, H = 1920, 1080
 sd = scenes.atrium_scene(4); sc = Scene(sd, 0); cam = Camera.for_scene(sd, (W, H))

@@ -166,10 +166,10 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
 // then all second ones, and so on, and the lane that finishes a slice stores the pixel's state — colour sum and RNG word, 32 bytes —
 // for whichever lane takes the next slice. The frame then drains over the length of the LAST slice. Per pixel the operations and their
 // order are untouched: same RNG sequence, same additions in the same order, bit-identical frame.
-//   state : per pixel of the tile two 16-byte words {sum r, g, b, tag} {RNG word, tag, -, -}, each written with ONE write-through
-//           (sc1) store and read with an sc1 load: a word is seen whole, and a reader takes the state only if BOTH tags say "written
-//           for the slice of this frame that starts with sample s" (tag0 + s; tag0 grows by more than spp from frame to frame, the
-//           buffer is never cleared).
+//   state : per pixel of the tile four 8-byte granules {value, tag} — sum r, g, b and the RNG word — written as two write-through (sc1)
+//           16-byte stores and read with two sc1 loads: "the data is the flag" (cdna_hip_programming.md §6, Guideline 16, R2). A reader
+//           takes the state only if ALL FOUR tags say "written for the slice of this frame that starts with sample s" (tag0 + s; tag0
+//           grows by more than spp from frame to frame, the buffer is never cleared): no flag, no fence, no ordering between the stores.
 //   order : slot q of the cursor = slice q / n_slots of pixel slot q % n_slots, so slice j of a pixel is handed out a whole sweep of the
 //           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it
 //           (mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) looks again in its wave's next
@@ -385,15 +385,15 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         }
         if (live && T.cur == kTravDone) {
             bool start = false; // this lane starts a path: a camera ray (src/render_megakernel.cpp:148-151)
-            if (SLICED && depth >= kPend) { // the state of the pixel: two 16-byte words, taken when both carry this slice's tag
+            if (SLICED && depth >= kPend) { // the state of the pixel: four {value, tag} granules, taken when all carry this slice's tag
                 const SliceNow sn = frame_slices(frame);
                 const auto rsrc = state_rsrc(sn);
                 const uint32_t at = pix * 32u, tag = sn.head.z + s;
                 const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
                 const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
-                if (w0.w == tag && w1.y == tag) {
-                    *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.y), *color_b = __uint_as_float(w0.z);
-                    rng = w1.x;
+                if (w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) {
+                    *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.z), *color_b = __uint_as_float(w1.x);
+                    rng = w1.z;
                     start = true;
                 }
             } else {
@@ -421,8 +421,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                         const auto rsrc = state_rsrc(sn);
                         const uint32_t at = pix * 32u, tag = sn.head.z + s;
                         u32x4 w0, w1;
-                        w0.x = __float_as_uint(*color_r), w0.y = __float_as_uint(*color_g), w0.z = __float_as_uint(*color_b), w0.w = tag;
-                        w1.x = rng, w1.y = tag, w1.z = 0u, w1.w = 0u;
+                        w0.x = __float_as_uint(*color_r), w0.y = tag, w0.z = __float_as_uint(*color_g), w0.w = tag;
+                        w1.x = __float_as_uint(*color_b), w1.y = tag, w1.z = rng, w1.w = tag;
                         __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, (int)at, 0, 16 /* sc1 */);
                         __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
                     } else if (s < spp) {

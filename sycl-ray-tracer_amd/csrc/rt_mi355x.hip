@@ -21,6 +21,7 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.h"
 #include "scene_build.h"
+#include "rt_knobs.h"
 
 using namespace rt;
 
@@ -307,10 +308,13 @@ bool wf_one_launch(const rt_renderer* r) { return r->sched.samples_per_launch ==
 // process environment (round 3 set the variable from a constructor: a side effect of dlopen, and void when HIP was already up). It READS what the
 // host configured when a renderer is created, and resolves an automatic lane count down to what the queues can serve: lanes + 2 <= queues. The
 // host (bench.py, the raytracer CLI) sets GPU_MAX_HW_QUEUES=8 itself before HIP starts; rt_stats reports both numbers.
-uint32_t hw_queues_from_env() {
-    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? (uint32_t)v : 4u; // HIP's default
+uint32_t hw_queues_from_env() { // read ONCE per process, at the library's first renderer: HIP latched the value at its own initialisation, and a
+    static const uint32_t queues = [] { // host that changes the variable later must not make the library report queues HIP does not serve
+        const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 ? (uint32_t)v : 4u; // HIP's default
+    }();
+    return queues;
 }
 uint32_t wf_stream_lanes(const rt_renderer* r) {
     if (r->sched.stream_lanes) return std::min(r->sched.stream_lanes, 8u); // explicit: the caller's business
@@ -371,7 +375,7 @@ hipError_t lane_stream_of(int device, uint32_t k, hipStream_t* out, bool* owned)
     int prio_lo = 0, prio_hi = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (e != hipSuccess) return e;
-    if (k >= kLanePool) { // beyond the pool (explicit stream_lanes > 4): a stream of the renderer's own
+    if (k >= kLanePool) { // beyond the pool (an explicit stream_lanes > 3): a stream of the renderer's own
         *owned = true;
         return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_hi);
     }
@@ -394,10 +398,10 @@ hipError_t lane_stream_of(int device, uint32_t k, hipStream_t* out, bool* owned)
 
 int alloc_tile_buffers_impl(rt_renderer* r) {
     free_tile_buffers(r);
-    // test hook: RT_INJECT_ALLOC_FAILURE=k makes the k-th device allocation of this call fail as if the device were out of memory
-    // (tests/test_gpu_parity.py: a failed re-allocation must leave a renderer that says so, not one that launches on null queues)
+    // test hook, DEVELOPER builds only (rt_knobs.h): RT_INJECT_ALLOC_FAILURE=k makes the k-th device allocation of this call fail as if the device
+    // were out of memory (tests/test_gpu_parity.py: a failed re-allocation must leave a renderer that says so, not one that launches on null queues)
     int inject = 0, n_alloc = 0;
-    if (const char* e = std::getenv("RT_INJECT_ALLOC_FAILURE")) inject = std::atoi(e);
+    if (const char* e = dev_knob("RT_INJECT_ALLOC_FAILURE")) inject = std::atoi(e);
     auto dalloc = [&](void** p, size_t bytes) { return inject && ++n_alloc == inject ? hipErrorOutOfMemory : hipMalloc(p, bytes); };
     r->tile.local_rows = rows_of_tile(r->tile, r->height);
     r->n_local = (uint32_t)r->tile.local_rows * (uint32_t)r->width;
@@ -531,8 +535,7 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
     }
     sl.shift = shift;
     sl.n_slices = n;
-#ifdef RT_DEVELOPER_KNOBS
-    if (const char* e = std::getenv("RT_MEGA_SLICE_BOUNDS")) { // sweeps: the samples slices 1, 2, ... start with, ascending, e.g. "48,60,63" (shift 0 only)
+    if (const char* e = dev_knob("RT_MEGA_SLICE_BOUNDS")) { // sweeps: the samples slices 1, 2, ... start with, ascending, e.g. "48,60,63" (shift 0 only)
         sl.cuts = 0, sl.n_slices = 1;
         for (uint32_t k = 0; k < kMaxSlices; ++k) sl.bound[k] = r->spp;
         uint32_t prev = 0;
@@ -543,7 +546,6 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
             sl.bound[sl.n_slices - 1] = v, sl.cuts |= 1ull << v, sl.n_slices++, prev = v;
         }
     }
-#endif
     return sl;
 }
 
@@ -566,12 +568,40 @@ hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i) {
 
 // The wavefront frame: every launch of the lanes' chains, forked from and joined back into `st`. Issued directly
 // or recorded by a stream capture (enqueue_frame).
-int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t st, LaunchCount* launches_out, size_t* n_hot_events) {
+// Under stream capture (rt_schedule::hip_graph) the frame's small fills and its camera upload are KERNEL nodes: as memset / memcpy nodes of a
+// replayed graph they were not reliable on ROCm 7.2 — from the third replay on, the queue-length words of a renderer whose buffers had been
+// re-allocated before the capture came back holding foreign 16-byte patterns (the frame still rendered, its ray count did not:
+// profiles/r05_graph_nodes.txt). A kernel reads the pinned host copy of the camera through its device address.
+__global__ void __launch_bounds__(256) k_fill_words(uint32_t* __restrict__ p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(64) k_copy_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+int fill_bytes(void* p, int byte, size_t bytes, hipStream_t st, bool capturing) { // bytes: a multiple of 4
+    if (!capturing) {
+        HIPCHK(hipMemsetAsync(p, byte, bytes, st));
+        return RT_OK;
+    }
+    const uint32_t n = (uint32_t)(bytes / 4), b = (uint32_t)(byte & 0xFF);
+    if (n) hipLaunchKernelGGL(k_fill_words, dim3((n + 255u) / 256u), dim3(256), 0, st, (uint32_t*)p, n, b * 0x01010101u);
+    return RT_OK;
+}
+
+int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t st, LaunchCount* launches_out, size_t* n_hot_events, bool capturing = false) {
     const SceneDev& S = r->scene->dev;
     LaunchCount launches;
-    HIPCHK(hipMemcpyAsync(r->d_cam, r->h_cam, sizeof(CameraDev), hipMemcpyHostToDevice, st));
+    if (capturing) {
+        static_assert(sizeof(CameraDev) % 4 == 0 && sizeof(CameraDev) / 4 <= 64, "k_copy_words copies the camera with one wave");
+        void* h_cam_dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&h_cam_dev, r->h_cam, 0));
+        hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, st, (uint32_t*)r->d_cam, (const uint32_t*)h_cam_dev, (uint32_t)(sizeof(CameraDev) / 4));
+    } else {
+        HIPCHK(hipMemcpyAsync(r->d_cam, r->h_cam, sizeof(CameraDev), hipMemcpyHostToDevice, st));
+    }
     const uint32_t D = r->max_depth;
-    if (r->d_stats) HIPCHK(hipMemsetAsync(r->d_stats, 0, 24 * sizeof(unsigned long long), st));
+    if (r->d_stats) { int rc_ = fill_bytes(r->d_stats, 0, 24 * sizeof(unsigned long long), st, capturing); if (rc_ != RT_OK) return rc_; }
     // fork: every lane's stream waits for what was enqueued on `st` so far, then runs its own chain
     if (r->lanes.size() > 1) HIPCHK(hipEventRecord(r->ev_fork, st));
     size_t ne_total = 0;
@@ -592,8 +622,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
         const uint32_t ext_waves = std::max<uint32_t>(1u, std::min<uint32_t>((L.n_local + kExtendChunk - 1u) / kExtendChunk,
                                                                             (uint32_t)r->n_cus * 4u * (r->wf_extend_occ ? r->wf_extend_occ : (K >= 2 ? kExtendWaves / 2 : kExtendWaves))));
         ext_grid[k] = (ext_waves + ext_wpb - 1u) / ext_wpb;
-        HIPCHK(hipMemsetAsync(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L)));
-        HIPCHK(hipMemsetAsync(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L)));
+        if (int rc_ = fill_bytes(L.d_counts, 0, (L.h_counts.size() + (size_t)r->spp * D + (size_t)r->spp + 1) * 4, lane_stream(L), capturing)) return rc_;
+        if (int rc_ = fill_bytes(L.d_extra, 0, L.h_extra.size() * 8, lane_stream(L), capturing)) return rc_;
         hipLaunchKernelGGL(k_wf_init, dim3(grid[k]), dim3(256), 0, lane_stream(L), r->d_cam, L.tile, r->seed_mode, L.n_local, L.d_rng, L.d_accum);
         launches.add(RT_K_WF_INIT);
     }
@@ -725,8 +755,8 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 const bool req = n_samples > 1 && L.d_rq_entries != nullptr;
                 FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, reinterpret_cast<uint32_t*>(L.d_extra + r->spp), L.rq_capacity};
                 if (req) { // the launch's dynamic queue: all entries invalid, counters zero
-                    HIPCHK(hipMemsetAsync(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls));
-                    HIPCHK(hipMemsetAsync(L.d_rq_ctl, 0, 80 * 4, ls));
+                    if (int rc_ = fill_bytes(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls, capturing)) return rc_;
+                    if (int rc_ = fill_bytes(L.d_rq_ctl, 0, 80 * 4, ls, capturing)) return rc_;
                 }
 #define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
     hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(kMegaBlock), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
@@ -843,7 +873,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                 drop_graph(r);
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-                const int rc = enqueue_wavefront(r, d_f32, d_u8, st, &r->graph_launches, &ne_total);
+                const int rc = enqueue_wavefront(r, d_f32, d_u8, st, &r->graph_launches, &ne_total, true);
                 const hipError_t ce = hipStreamEndCapture(st, &g); // also ends a capture that failed half-way
                 if (rc != RT_OK || ce != hipSuccess || !g) {
                     if (g) (void)hipGraphDestroy(g);
@@ -963,6 +993,17 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                 }
             }
             local.rays = rays;
+#ifdef RT_DEBUG_COUNTS
+            if (rays > (uint64_t)r->n_local * r->spp * r->max_depth) {
+                for (auto& L : r->lanes) {
+                    std::fprintf(stderr, "[debug] counts:");
+                    for (size_t i = 0; i < L.h_counts.size(); ++i) std::fprintf(stderr, " %u", L.h_counts[i]);
+                    std::fprintf(stderr, "\n[debug] extra:");
+                    for (size_t i = 0; i < L.h_extra.size(); ++i) std::fprintf(stderr, " %llu", (unsigned long long)L.h_extra[i]);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+#endif
         }
     }
     if (r->d_stats && r->n_local) {
@@ -1194,8 +1235,8 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     r->hw_queues = hw_queues_from_env();
     const char* prof = std::getenv("RT_PROFILE_KERNELS");
     r->profile_kernels = prof && prof[0] == '1';
-    if (const char* e = std::getenv("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
-    if (const char* e = std::getenv("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
+    if (const char* e = dev_knob("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
+    if (const char* e = dev_knob("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
     auto bail = [&](int code) {
         rt_renderer_destroy(r);
         return code;
@@ -1218,24 +1259,24 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     if (kind == RT_RENDERER_WAVEFRONT) {
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
-        // Environment shim for scripts (the API is rt_renderer_set_schedule; tests use that): the variables fill the initial schedule.
+        // Environment shim for sweep scripts, DEVELOPER builds only (rt_knobs.h; the API is rt_renderer_set_schedule): the variables fill the initial schedule.
         // RT_WF_STREAMS / RT_WF_REQUEUE alone have always meant "not the one-launch schedule": they imply a launch per sample.
         rt_schedule& sc = r->sched;
-        if (const char* e = std::getenv("RT_WF_GRAPH")) sc.hip_graph = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_FINISH_DEPTH")) sc.finish_depth = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RT_WF_SAMPLES_PER_LAUNCH")) sc.samples_per_launch = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RT_WF_REQUEUE")) sc.requeue = e[0] != '0' ? 1 : 0;
-        if (const char* e = std::getenv("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
-        if ((std::getenv("RT_WF_REQUEUE") || std::getenv("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
-        if (const char* e = std::getenv("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
-        if (const char* e = std::getenv("RT_WF_EXTEND_OCC")) r->wf_extend_occ = (uint32_t)std::max(1, std::min((int)kExtendWaves, std::atoi(e)));
-        if (const char* e = std::getenv("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
-        if (const char* e = std::getenv("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
-        if (const char* e = std::getenv("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_SHOOT_STATIC_PCT")) r->wf_shoot_static_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));
-        if (const char* e = std::getenv("RT_WF_REORDER")) sc.reorder = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
-        if (const char* e = std::getenv("RT_WF_FUSED_BOUNCE")) sc.fused_bounce = e[0] == '1';
+        if (const char* e = dev_knob("RT_WF_GRAPH")) sc.hip_graph = e[0] == '1';
+        if (const char* e = dev_knob("RT_WF_FINISH_DEPTH")) sc.finish_depth = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = dev_knob("RT_WF_SAMPLES_PER_LAUNCH")) sc.samples_per_launch = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = dev_knob("RT_WF_REQUEUE")) sc.requeue = e[0] != '0' ? 1 : 0;
+        if (const char* e = dev_knob("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+        if ((dev_knob("RT_WF_REQUEUE") || dev_knob("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
+        if (const char* e = dev_knob("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
+        if (const char* e = dev_knob("RT_WF_EXTEND_OCC")) r->wf_extend_occ = (uint32_t)std::max(1, std::min((int)kExtendWaves, std::atoi(e)));
+        if (const char* e = dev_knob("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
+        if (const char* e = dev_knob("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
+        if (const char* e = dev_knob("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
+        if (const char* e = dev_knob("RT_WF_SHOOT_STATIC_PCT")) r->wf_shoot_static_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));
+        if (const char* e = dev_knob("RT_WF_REORDER")) sc.reorder = e[0] == '1';
+        if (const char* e = dev_knob("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
+        if (const char* e = dev_knob("RT_WF_FUSED_BOUNCE")) sc.fused_bounce = e[0] == '1';
     }
     rc = no_throw([&] { return alloc_tile_buffers(r); });
     if (rc != RT_OK) return bail(rc);
@@ -1529,6 +1570,7 @@ int rt_frame_gather_begin(rt_comm* c, rt_renderer* const* rs, int want_f32, int 
         const rt_renderer* r = rs[i];
         if (!r) return fail(RT_ERR_INVALID, "null renderer");
         if (r->frame_pending) return fail(RT_ERR_INVALID, "a renderer still has a frame in flight (rt_render_frame_end first)");
+        if (r->unusable) return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " has no buffers: its last rt_renderer_set_tile / rt_renderer_set_schedule failed (call either again)");
         if (r->scene->device != c->devices[i]) return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " is not on the communicator's device " + std::to_string(c->devices[i]));
         if (r->width != rs[0]->width || r->height != rs[0]->height) return fail(RT_ERR_INVALID, "renderers differ in frame size");
         if (r->tile.world != n || r->tile.rank != i || r->tile.strip_rows != rs[0]->tile.strip_rows)

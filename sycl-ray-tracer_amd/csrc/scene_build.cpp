@@ -8,6 +8,7 @@
 // Compiled with -ffp-contract=off: the world-space vertices and edges computed here are part of
 // the arithmetic contract shared with the CPU oracle (instance transform row order, e1 = v1 - v0).
 #include "scene_build.h"
+#include "rt_knobs.h"
 
 #include <algorithm>
 #include <array>
@@ -296,7 +297,7 @@ void build_sah(Builder& b, uint32_t max_sah_depth) {
     constexpr int NB = 32;
     // cost of one traversal step relative to one triangle test, for the leaf-vs-split decision of small ranges
     float trav_cost = 1.0f;
-    if (const char* e = std::getenv("RT_SAH_TRAV_COST")) trav_cost = (float)std::atof(e);
+    if (const char* e = dev_knob("RT_SAH_TRAV_COST")) trav_cost = (float)std::atof(e);
     struct Work {
         int32_t node;
         uint32_t first, count, depth;
@@ -783,14 +784,14 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         // built too and the one with the lower surface-area cost is kept (a 116-triangle Cornell box gets worse, a tilted hall 15 % better).
         // RT_BVH_SPLIT_BUDGET=0 switches it off, RT_BVH_SPLIT_FLOOR=<fraction of the scene extent> moves the floor.
         double budget = 0.3, floor_frac = 1.0 / 64.0;
-        if (const char* e = std::getenv("RT_BVH_SPLIT_BUDGET")) budget = std::max(0.0, std::min(4.0, std::atof(e)));
-        if (const char* e = std::getenv("RT_BVH_SPLIT_FLOOR")) floor_frac = std::max(1e-4, std::min(1.0, std::atof(e)));
+        if (const char* e = dev_knob("RT_BVH_SPLIT_BUDGET")) budget = std::max(0.0, std::min(4.0, std::atof(e)));
+        if (const char* e = dev_knob("RT_BVH_SPLIT_FLOOR")) floor_frac = std::max(1e-4, std::min(1.0, std::atof(e)));
         // one pass over the larger half of the inner nodes: -2.6 % SAH cost, 17.9 -> 17.5 node visits per ray on the
         // atrium (+0.7 % rays/s) for 0.18 s of extra build time; further passes change nothing. RT_BVH_REINSERT=0: off
         int passes = 1;
         double fraction = 0.5;
-        if (const char* e = std::getenv("RT_BVH_REINSERT")) passes = std::atoi(e);
-        if (const char* e = std::getenv("RT_BVH_REINSERT_FRACTION")) fraction = std::atof(e);
+        if (const char* e = dev_knob("RT_BVH_REINSERT")) passes = std::atoi(e);
+        if (const char* e = dev_knob("RT_BVH_REINSERT_FRACTION")) fraction = std::atof(e);
         auto run = [&](Builder& bb, bool split) {
             if (split && bvh_kind != RT_BVH_MEDIAN_INTERNAL && budget > 0.0) presplit(bb, budget, (float)(floor_frac * (double)ext));
             build_sah(bb, bvh_kind == RT_BVH_MEDIAN_INTERNAL ? 0u : 48u);
@@ -868,7 +869,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
     // takes one slot is a leaf or a BVH4 node of its own (area + the best way to hand its 4 slots to its two halves).
     // cut[n][4] = slots a BVH4 node n gives to its LEFT half. RT_BVH_COLLAPSE=greedy restores the open-the-largest-child rule.
     bool use_dp = true;
-    if (const char* e = std::getenv("RT_BVH_COLLAPSE")) use_dp = std::string(e) != "greedy";
+    if (const char* e = dev_knob("RT_BVH_COLLAPSE")) use_dp = std::string(e) != "greedy";
     std::vector<std::array<float, 5>> best;
     std::vector<std::array<uint8_t, 5>> cut;
     if (use_dp) collapse_dp(b, best, cut);
@@ -950,7 +951,7 @@ int build_host_scene(const rt_scene_desc* d, int bvh_kind, HostScene& hs, std::s
         hs.nodes[it.slot] = out;
     }
     hs.sah_cost = cost;
-    if (const char* e = std::getenv("RT_BVH_VERBOSE")) { // diagnostic: leaves by size
+    if (const char* e = dev_knob("RT_BVH_VERBOSE")) { // diagnostic: leaves by size
         if (e[0] == '1') {
             size_t by[5] = {0, 0, 0, 0, 0};
             for (const BvhNode& n : hs.nodes)

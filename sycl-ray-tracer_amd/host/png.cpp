@@ -2,7 +2,7 @@
 //
 // write_png_rgba8 stands in for stbi_write_png("out.png", w, h, 4, buf, w*4) (src/util.hpp:27);
 // decode_png_rgba8 stands in for tinygltf's stb_image decode to 4 channels (deps/include/tiny_gltf.h:2610).
-// Non-interlaced PNG, bit depth 8 or 16, colour types 0/2/3/4/6. JPEG textures are not supported.
+// Bit depth 8 or 16, colour types 0/2/3/4/6 (JPEG textures: jpeg.cpp).
 #include "png.h"
 
 #include <zlib.h>

@@ -211,10 +211,25 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     return lib
 
 
-def check(status: int) -> None:
+def check(status: int, lib: C.CDLL | None = None) -> None:
+    """`lib`: the library the failing call was made through (its rt_last_error() is per library and thread); default: the product library."""
     if status != RT_OK:
-        msg = load_library().rt_last_error()
+        msg = (lib or load_library()).rt_last_error()
         raise RtError(status, msg.decode() if msg else "")
+
+
+DEV_LIB_PATH = PKG_DIR / "csrc" / "build" / "librt_mi355x_dev.so"
+_dev_lib = None
+
+
+def load_developer_library() -> C.CDLL:
+    """librt_mi355x_dev.so (`make -C sycl-ray-tracer_amd/csrc dev`): the same sources with -DRT_DEVELOPER_KNOBS — the build whose tuning knobs and
+    test hooks (RT_WF_*, RT_MEGA_*, RT_BVH_*, RT_INJECT_ALLOC_FAILURE) read the environment. Tests of those hooks and the sweep scripts use it
+    (Scene(..., lib=...)); the product library reads GPU_MAX_HW_QUEUES, RT_PROFILE_KERNELS and RT_KERNEL_STATS only."""
+    global _dev_lib
+    if _dev_lib is None:
+        _dev_lib = load_library(DEV_LIB_PATH)
+    return _dev_lib
 
 
 def fptr(a):

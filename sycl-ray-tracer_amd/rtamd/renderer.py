@@ -38,21 +38,22 @@ class Camera:
 class Scene:
     """Device-resident scene: == what raytracer::Scene hands the kernels (RTCScene + GeometryData)."""
 
-    def __init__(self, desc: SceneDesc, device: int = 0, bvh: int = abi.RT_BVH_DEFAULT):
+    def __init__(self, desc: SceneDesc, device: int = 0, bvh: int = abi.RT_BVH_DEFAULT, lib=None):
+        """`lib`: another build of the library (abi.load_developer_library()); renderers of this scene use the same one."""
         self.desc = desc
         self.device = device
-        self._lib = abi.load_library()
+        self._lib = lib or abi.load_library()
         self._c = desc.to_c()
         self.h = C.c_void_p()
-        abi.check(self._lib.rt_scene_create(C.byref(self._c), device, bvh, C.byref(self.h)))
+        abi.check(self._lib.rt_scene_create(C.byref(self._c), device, bvh, C.byref(self.h)), self._lib)
 
     def info(self) -> abi.rt_scene_info_t:
         out = abi.rt_scene_info_t()
-        abi.check(self._lib.rt_scene_info(self.h, C.byref(out)))
+        abi.check(self._lib.rt_scene_info(self.h, C.byref(out)), self._lib)
         return out
 
     def check_bvh(self) -> None:
-        abi.check(self._lib.rt_scene_check_bvh(self.h))
+        abi.check(self._lib.rt_scene_check_bvh(self.h), self._lib)
 
     def intersect(self, org: np.ndarray, dirs: np.ndarray):
         org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
@@ -61,7 +62,7 @@ class Scene:
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
         tri = np.zeros(n, np.uint32)
         abi.check(self._lib.rt_intersect_batch(self.h, n, abi.fptr(org), abi.fptr(dirs), abi.fptr(t), abi.fptr(u),
-                                               abi.fptr(v), abi.u32ptr(tri)))
+                                               abi.fptr(v), abi.u32ptr(tri)), self._lib)
         return t, u, v, tri
 
     def scatter(self, material: int, dirs, normals, uvs, seeds):
@@ -74,7 +75,7 @@ class Scene:
         od, oa = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
         so = np.zeros(n, np.uint32)
         abi.check(self._lib.rt_probe_scatter(self.h, material, n, abi.fptr(dirs), abi.fptr(normals), abi.fptr(uvs),
-                                             abi.u32ptr(seeds), abi.u8ptr(ok), abi.fptr(od), abi.fptr(oa), abi.u32ptr(so)))
+                                             abi.u32ptr(seeds), abi.u8ptr(ok), abi.fptr(od), abi.fptr(oa), abi.u32ptr(so)), self._lib)
         return ok, od, oa, so
 
     def close(self):
@@ -131,20 +132,20 @@ class IRenderer:
         self.scene = scene
         self.img_size = (int(img_size[0]), int(img_size[1]))
         self.max_depth, self.sample_count = int(max_depth), int(sample_count)
-        self._lib = abi.load_library()
+        self._lib = scene._lib
         self.h = C.c_void_p()
         abi.check(self._lib.rt_renderer_create(self.KIND, scene.h, self.img_size[0], self.img_size[1], self.max_depth,
-                                               self.sample_count, seed_mode, C.byref(self.h)))
+                                               self.sample_count, seed_mode, C.byref(self.h)), self._lib)
 
     def set_tile(self, rank: int, world: int, strip_rows: int = 8) -> None:
-        abi.check(self._lib.rt_renderer_set_tile(self.h, rank, world, strip_rows))
+        abi.check(self._lib.rt_renderer_set_tile(self.h, rank, world, strip_rows), self._lib)
 
     def set_profiling(self, enable: bool) -> None:
-        abi.check(self._lib.rt_renderer_set_profiling(self.h, int(enable)))
+        abi.check(self._lib.rt_renderer_set_profiling(self.h, int(enable)), self._lib)
 
     def set_russian_roulette(self, start_bounce: int) -> None:
         """Extension (a to-do upstream: PLAN.md:23-27): paths are thinned from bounce `start_bounce` on; 0 = off (default)."""
-        abi.check(self._lib.rt_renderer_set_russian_roulette(self.h, int(start_bounce)))
+        abi.check(self._lib.rt_renderer_set_russian_roulette(self.h, int(start_bounce)), self._lib)
 
     def set_schedule(self, finish_depth: int = 0, samples_per_launch: int = 0, stream_lanes: int = 0, requeue: int = -1,
                      reorder: bool = False, matsort: bool = False, cost_order: int = -1, hip_graph: bool = False,
@@ -154,11 +155,11 @@ class IRenderer:
         Frame.kernels reports what ran. The megakernel uses pixel_slices only (-1 automatic, 0 / 1 off, 2 .. 8: rt_mi355x.h)."""
         sc = abi.rt_schedule(int(finish_depth), int(samples_per_launch), int(stream_lanes), int(requeue), int(bool(reorder)),
                              int(bool(matsort)), int(cost_order), int(bool(hip_graph)), int(bool(fused_bounce)), int(pixel_slices))
-        abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)))
+        abi.check(self._lib.rt_renderer_set_schedule(self.h, C.byref(sc)), self._lib)
 
     def get_schedule(self) -> abi.rt_schedule:
         sc = abi.rt_schedule()
-        abi.check(self._lib.rt_renderer_get_schedule(self.h, C.byref(sc)))
+        abi.check(self._lib.rt_renderer_get_schedule(self.h, C.byref(sc)), self._lib)
         return sc
 
     @property
@@ -176,25 +177,25 @@ class IRenderer:
         b = np.zeros((rows, w, 4), np.uint8) if want_u8 else None
         st = abi.rt_stats()
         abi.check(self._lib.rt_render_frame(self.h, C.byref(camera.c), abi.fptr(f) if want_f32 else None,
-                                            abi.u8ptr(b) if want_u8 else None, C.byref(st)))
+                                            abi.u8ptr(b) if want_u8 else None, C.byref(st)), self._lib)
         return Frame.from_stats(f, b, st)
 
     def render_frame_device(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> Frame:
         """Outputs go to DEVICE pointers (e.g. torch tensor .data_ptr()); nothing is copied to host."""
         st = abi.rt_stats()
         abi.check(self._lib.rt_render_frame_device(self.h, C.byref(camera.c), C.c_void_p(d_f32 or None),
-                                                   C.c_void_p(d_u8 or None), C.c_void_p(stream or None), C.byref(st)))
+                                                   C.c_void_p(d_u8 or None), C.c_void_p(stream or None), C.byref(st)), self._lib)
         return Frame.from_stats(None, None, st)
 
     def begin_frame(self, camera: Camera, d_f32: int = 0, d_u8: int = 0, stream: int = 0) -> None:
         """Enqueues the frame and returns at once; collect it with end_frame(). Frames of different renderers overlap on
         the device (the next frame's waves move in while this one's last pixels drain)."""
         abi.check(self._lib.rt_render_frame_begin(self.h, C.byref(camera.c), C.c_void_p(d_f32 or None), C.c_void_p(d_u8 or None),
-                                                  C.c_void_p(stream or None)))
+                                                  C.c_void_p(stream or None)), self._lib)
 
     def end_frame(self) -> Frame:
         st = abi.rt_stats()
-        abi.check(self._lib.rt_render_frame_end(self.h, C.byref(st)))
+        abi.check(self._lib.rt_render_frame_end(self.h, C.byref(st)), self._lib)
         return Frame.from_stats(None, None, st)
 
     def close(self):
@@ -223,12 +224,12 @@ class TileComm:
     SURVEY §8e). With the same device listed more than once (a rehearsal of an N-GPU split on fewer GPUs) RCCL cannot be used
     (one rank per device) and the strips move by device copies instead: `uses_rccl` tells which."""
 
-    def __init__(self, devices):
-        self._lib = abi.load_library()
+    def __init__(self, devices, lib=None):
+        self._lib = lib or abi.load_library()
         self.devices = [int(d) for d in devices]
         arr = (C.c_int * len(self.devices))(*self.devices)
         self.h = C.c_void_p()
-        abi.check(self._lib.rt_comm_create(len(self.devices), arr, C.byref(self.h)))
+        abi.check(self._lib.rt_comm_create(len(self.devices), arr, C.byref(self.h)), self._lib)
 
     @property
     def uses_rccl(self) -> bool:
@@ -247,7 +248,7 @@ class TileComm:
         f = np.zeros((h, w, 4), np.float32) if want_f32 else None
         b = np.zeros((h, w, 4), np.uint8) if want_u8 else None
         hs = (C.c_void_p * n)(*[r.h for r in renderers])
-        abi.check(self._lib.rt_frame_gather(self.h, hs, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None, 0, 0))
+        abi.check(self._lib.rt_frame_gather(self.h, hs, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None, 0, 0), self._lib)
         return f, b, rays
 
     @property
@@ -258,14 +259,14 @@ class TileComm:
         """rt_frame_gather_begin: enqueues the gather of the renderers' collected frames (no host wait); the renderers may begin their
         next frame right away."""
         hs = (C.c_void_p * len(renderers))(*[r.h for r in renderers])
-        abi.check(self._lib.rt_frame_gather_begin(self.h, hs, int(want_f32), int(want_u8)))
+        abi.check(self._lib.rt_frame_gather_begin(self.h, hs, int(want_f32), int(want_u8)), self._lib)
 
     def wait(self, shape, want_f32: bool = True, want_u8: bool = True):
         """rt_comm_wait: blocks until the gathered frame is complete on the root device and returns host copies of it."""
         h, w = shape
         f = np.zeros((h, w, 4), np.float32) if want_f32 else None
         b = np.zeros((h, w, 4), np.uint8) if want_u8 else None
-        abi.check(self._lib.rt_comm_wait(self.h, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None))
+        abi.check(self._lib.rt_comm_wait(self.h, abi.fptr(f) if want_f32 else None, abi.u8ptr(b) if want_u8 else None), self._lib)
         return f, b
 
     def close(self):

@@ -35,6 +35,17 @@ def rtlib():
 
 
 @pytest.fixture(scope="session")
+def devlib(rtlib):
+    """librt_mi355x_dev.so: the -DRT_DEVELOPER_KNOBS build (csrc/rt_knobs.h), the only one whose sweep knobs and test hooks read the
+    environment. Tests of those knobs and hooks load it beside the product library (Scene(..., lib=devlib))."""
+    from rtamd import abi
+    if not abi.DEV_LIB_PATH.exists():
+        import __graft_entry__ as g
+        g.build()
+    return abi.load_developer_library()
+
+
+@pytest.fixture(scope="session")
 def scene_cache():
     from rtamd import scenes
     cache = {}

@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol(rtlib):
     assert rtlib.rt_abi_version() == 8
 
 
+def test_product_library_reads_three_environment_variables_only(rtlib, devlib):
+    """sweep knobs and test hooks are compiled into the developer build only (csrc/rt_knobs.h). Every NAME the library could
+    hand to getenv() is a string in its binary: the product's are GPU_MAX_HW_QUEUES, RT_PROFILE_KERNELS, RT_KERNEL_STATS; the developer
+    build's include the knobs the sweep scripts and the hook tests use. Host-side check of the injected-failure hook: only the developer build has it."""
+    def env_names(path):
+        return set(m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])((?:RT|GPU)_[A-Z0-9_]{4,})\x00", Path(path).read_bytes()))
+    product, dev = env_names(abi.LIB_PATH), env_names(abi.DEV_LIB_PATH)
+    assert product == {"GPU_MAX_HW_QUEUES", "RT_PROFILE_KERNELS", "RT_KERNEL_STATS"}, product
+    assert {"RT_INJECT_ALLOC_FAILURE", "RT_WF_FINISH_DEPTH", "RT_MEGA_OCC", "RT_BVH_SPLIT_BUDGET", "RT_MEGA_SLICE_BOUNDS"} <= dev and product <= dev
+    assert devlib.rt_abi_version() == rtlib.rt_abi_version()
+    for n in _declared_functions():
+        assert hasattr(devlib, n)
+
+
 def test_struct_layouts_match_header(tmp_path):
     """ctypes mirrors vs the real header, measured by compiling a C program against include/rt_mi355x.h."""
     import subprocess
@@ -204,7 +218,8 @@ def test_atrium_generator_is_deterministic():
     assert a.textures.shape[0] == 9
 
 
-def test_presplitting_large_diagonal_triangles_lowers_the_tree_cost_and_keeps_it_valid(rtlib, scene_cache, monkeypatch):
+def test_presplitting_large_diagonal_triangles_lowers_the_tree_cost_and_keeps_it_valid(devlib, scene_cache, monkeypatch):
+    rtlib = devlib  # the builder's parameters are environment knobs of the developer build
     """The SAH builder's pre-splitting pass (VERDICT r2 item 4a: spatial splits; here early split clipping with a budget): triangles whose
     boxes enclose much empty space are cut into clipped references before the build. On the tilted atrium with two-triangle walls the
     tree's surface-area cost drops; the check requires every record's piece box inside its leaf and the pieces of every split triangle to
@@ -245,7 +260,8 @@ def test_voxel_generator_is_deterministic_and_meshes_only_visible_faces():
     assert len(np.unique(keys)) == a.n_triangles                 # no duplicates
 
 
-def test_builder_stages_keep_the_tree_valid_and_do_not_raise_its_cost(rtlib, scene_cache, monkeypatch):
+def test_builder_stages_keep_the_tree_valid_and_do_not_raise_its_cost(devlib, scene_cache, monkeypatch):
+    rtlib = devlib  # the builder's parameters are environment knobs of the developer build
     """The two post-passes of the SAH builder — insertion-based optimisation of the binary tree and the dynamic-programming
     collapse to four children — each leave a structurally valid BVH (every decoded box contains its subtree) and a
     surface-area cost no higher than without them; RT_BVH_REINSERT=0 / RT_BVH_COLLAPSE=greedy switch them off."""
