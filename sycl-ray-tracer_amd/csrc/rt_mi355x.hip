@@ -469,7 +469,9 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
                 HIPCHK(dalloc((void**)&L.d_rq_entries, (size_t)L.rq_capacity * 8));
                 HIPCHK(dalloc((void**)&L.d_rq_ctl, 80 * 4));
             }
-            HIPCHK(lane_stream_of(r->scene->device, k, &L.stream, &L.stream_owned));
+            // (a frame captured into a hipGraph forks into its lanes' streams and puts them into capture mode: such a renderer gets lane
+            // streams of its OWN — on the device's shared pool another renderer's launches would be captured into this graph, or fail)
+            HIPCHK(lane_stream_of(r->scene->device, r->sched.hip_graph && K > 1 ? kLanePool + k : k, &L.stream, &L.stream_owned));
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
     }
