@@ -140,6 +140,13 @@ int rt_scene_info(const rt_scene* scene, rt_scene_info_t* out);
  * box inside its parent's, every triangle inside its leaf box. Returns RT_OK or RT_ERR_INVALID
  * (message names the first violation). Needs no GPU. */
 int rt_scene_check_bvh(const rt_scene* scene);
+/* Diagnostic, host only (works on a scene built with device < 0): closest-hit walks of the tree for n rays as the traversal kernels make them
+ * (children nearest first, culled by the closest hit so far), counting node visits and triangle tests, with a choice of the child boxes
+ * tested: mode 0 the decoded 8-bit quantised boxes (what the kernels test), 1 the exact padded bounds of each child's subtree (what fp32
+ * boxes would hold), 2 the exact bounds re-quantised with two more bits per plane. t / tri (may be NULL) receive the closest hits. The
+ * difference between the modes is what the quantisation costs in visits on a given scene and ray set (profiles/r05_quantisation.txt). */
+int rt_scene_count_visits(const rt_scene* scene, uint32_t n, const float* org, const float* dir, int mode,
+                          uint64_t* node_visits, uint64_t* tri_tests, float* t, uint32_t* tri);
 
 /* Closest-hit query for a batch of rays: the replacement for rtcIntersect1 at
  * src/trace_ray.hpp:18-27 (tnear = 1e-4, tfar = +inf, no culling, no masks).

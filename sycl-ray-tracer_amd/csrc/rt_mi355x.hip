@@ -1185,6 +1185,14 @@ int rt_scene_check_bvh(const rt_scene* s) {
     return rc == RT_OK ? RT_OK : fail(rc, err);
 }
 
+int rt_scene_count_visits(const rt_scene* s, uint32_t n, const float* org, const float* dir, int mode, uint64_t* node_visits, uint64_t* tri_tests,
+                          float* t, uint32_t* tri) {
+    if (!s || (n && (!org || !dir))) return fail(RT_ERR_INVALID, "null argument");
+    std::string err;
+    const int rc = no_throw([&] { return count_visits(s->hs, n, org, dir, mode, node_visits, tri_tests, t, tri, err); });
+    return rc == RT_OK ? RT_OK : fail(rc, err.empty() ? g_err : err);
+}
+
 int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* dir, float* t, float* u, float* v,
                        uint32_t* tri) {
     if (!s || (n && (!org || !dir || !t || !u || !v || !tri))) return fail(RT_ERR_INVALID, "null argument");

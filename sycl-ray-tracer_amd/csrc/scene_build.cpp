@@ -1064,3 +1064,122 @@ int check_bvh(const HostScene& hs, std::string& err) {
 }
 
 } // namespace rt
+
+// ---- diagnostic: node visits of a closest-hit walk on the host (rt_scene_count_visits) --------------------------------------------------------
+// The walk the traversal kernels make — children entered nearest first, the others stacked, everything beyond the closest hit so far culled —
+// with a choice of the child boxes it tests:
+//   mode 0  the decoded quantised boxes, as the kernels test them
+//   mode 1  the exact bounds of each child's subtree, padded as the builder pads them: what an unquantised (fp32) node would hold
+//   mode 2  the exact padded bounds re-quantised on the node's grid with 2 more bits per plane (step / 4)
+// so that the share of the visits that is the price of 8-bit planes can be read off. Counts only: no result of a
+// render depends on it.
+namespace rt {
+int count_visits(const HostScene& hs, uint32_t n, const float* org, const float* dir, int mode, uint64_t* node_visits, uint64_t* tri_tests, float* t_out,
+                 uint32_t* tri_out, std::string& err) {
+    if (mode < 0 || mode > 2) { err = "mode: 0 quantised, 1 exact, 2 quantised with two more bits"; return RT_ERR_INVALID; }
+    if (hs.nodes.empty()) { err = "no tree"; return RT_ERR_INVALID; }
+    const float inf = std::numeric_limits<float>::infinity();
+    const bool split = hs.rec_lo.size() == 3 * hs.tris.size() && hs.rec_hi.size() == 3 * hs.tris.size() && hs.n_split_triangles > 0;
+    struct B { float lo[3], hi[3]; };
+    std::vector<B> box(hs.nodes.size() * 4); // the box tested for child k of node i
+    std::function<B(int32_t)> walk = [&](int32_t child) -> B {
+        B r;
+        for (int a = 0; a < 3; ++a) r.lo[a] = inf, r.hi[a] = -inf;
+        if (child >= 0) {
+            const BvhNode& nd = hs.nodes[(size_t)child];
+            for (int k = 0; k < 4; ++k) {
+                if (nd.child[k] == kChildEmpty) continue;
+                const B c = walk(nd.child[k]);
+                B& out = box[(size_t)child * 4 + k];
+                for (int a = 0; a < 3; ++a) {
+                    r.lo[a] = std::min(r.lo[a], c.lo[a]), r.hi[a] = std::max(r.hi[a], c.hi[a]);
+                    const float s = nd.scale(a);
+                    if (mode == 0) {
+                        out.lo[a] = nd.origin[a] + (float)((nd.q[2 * a] >> (8 * k)) & 0xffu) * s;
+                        out.hi[a] = nd.origin[a] + (float)((nd.q[2 * a + 1] >> (8 * k)) & 0xffu) * s;
+                    } else if (mode == 1) {
+                        out.lo[a] = c.lo[a] - hs.pad, out.hi[a] = c.hi[a] + hs.pad;
+                    } else {
+                        const float q = s * 0.25f;
+                        out.lo[a] = nd.origin[a] + std::floor((c.lo[a] - hs.pad - nd.origin[a]) / q) * q;
+                        out.hi[a] = nd.origin[a] + std::ceil((c.hi[a] + hs.pad - nd.origin[a]) / q) * q;
+                    }
+                }
+            }
+        } else {
+            const uint32_t code = (uint32_t)~child, first = code >> 2, count = (code & 3u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                if (split) {
+                    for (int a = 0; a < 3; ++a)
+                        r.lo[a] = std::min(r.lo[a], hs.rec_lo[3 * (size_t)(first + k) + a]), r.hi[a] = std::max(r.hi[a], hs.rec_hi[3 * (size_t)(first + k) + a]);
+                } else {
+                    const float* w = &hs.wverts[9 * (size_t)hs.tris[first + k].global_index];
+                    for (int v = 0; v < 3; ++v)
+                        for (int a = 0; a < 3; ++a) r.lo[a] = std::min(r.lo[a], w[3 * v + a]), r.hi[a] = std::max(r.hi[a], w[3 * v + a]);
+                }
+            }
+        }
+        return r;
+    };
+    (void)walk(0);
+    uint64_t visits = 0, tests = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float o[3] = {org[3 * i], org[3 * i + 1], org[3 * i + 2]}, d[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
+        float inv[3];
+        for (int a = 0; a < 3; ++a) inv[a] = 1.0f / (std::fabs(d[a]) < 1e-30f ? std::copysign(1e-30f, d[a]) : d[a]);
+        float best = inf;
+        uint32_t best_tri = kNoTri;
+        int32_t stack[kStackSize * 4];
+        int sp = 0;
+        int32_t cur = 0;
+        for (;;) {
+            if (cur >= 0) {
+                visits++;
+                const BvhNode& nd = hs.nodes[(size_t)cur];
+                float key[4];
+                int32_t ch[4];
+                int m = 0;
+                for (int k = 0; k < 4; ++k) {
+                    if (nd.child[k] == kChildEmpty) continue;
+                    const B& b = box[(size_t)cur * 4 + k];
+                    float tn = 0.0f, tf = best;
+                    for (int a = 0; a < 3; ++a) {
+                        const float t0 = (b.lo[a] - o[a]) * inv[a], t1 = (b.hi[a] - o[a]) * inv[a];
+                        tn = std::max(tn, std::min(t0, t1)), tf = std::min(tf, std::max(t0, t1));
+                    }
+                    if (tn <= tf) key[m] = tn, ch[m] = nd.child[k], m++;
+                }
+                for (int a = 1; a < m; ++a) // nearest first
+                    for (int b = a; b > 0 && key[b] < key[b - 1]; --b) std::swap(key[b], key[b - 1]), std::swap(ch[b], ch[b - 1]);
+                for (int a = m - 1; a >= 1; --a) stack[sp++] = ch[a];
+                if (m) { cur = ch[0]; continue; }
+            } else {
+                const uint32_t code = (uint32_t)~cur, first = code >> 2, count = (code & 3u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    tests++;
+                    const TriRec& tr = hs.tris[first + k];
+                    // Moller-Trumbore on (v0, e1, e2), in double: only the count matters here
+                    const double e1[3] = {tr.e1[0], tr.e1[1], tr.e1[2]}, e2[3] = {tr.e2[0], tr.e2[1], tr.e2[2]};
+                    const double p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+                    const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+                    if (det == 0.0) continue;
+                    const double tv[3] = {o[0] - tr.v0[0], o[1] - tr.v0[1], o[2] - tr.v0[2]};
+                    const double u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) / det;
+                    const double q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+                    const double v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) / det;
+                    if (u < 0.0 || v < 0.0 || u + v > 1.0) continue;
+                    const double t = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) / det;
+                    if (t > (double)kTNear && (t < best || (t == best && tr.global_index < best_tri))) best = (float)t, best_tri = tr.global_index;
+                }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+        if (t_out) t_out[i] = best;
+        if (tri_out) tri_out[i] = best_tri;
+    }
+    if (node_visits) *node_visits = visits;
+    if (tri_tests) *tri_tests = tests;
+    return RT_OK;
+}
+} // namespace rt

@@ -40,4 +40,8 @@ int build_lbvh_gpu(HostScene& hs, const std::vector<TriRec>& gtris, std::string&
 // Structural check used by rt_scene_check_bvh.
 int check_bvh(const HostScene& hs, std::string& err);
 
+// Diagnostic used by rt_scene_count_visits: closest-hit walks on the host with quantised (0), exact (1) or finer quantised (2) child boxes.
+int count_visits(const HostScene& hs, uint32_t n, const float* org, const float* dir, int mode, uint64_t* node_visits, uint64_t* tri_tests, float* t_out,
+                 uint32_t* tri_out, std::string& err);
+
 } // namespace rt

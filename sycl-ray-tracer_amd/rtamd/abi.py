@@ -143,6 +143,8 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_info": (C.c_int, [C.c_void_p, _P(rt_scene_info_t)]),
     "rt_scene_check_bvh": (C.c_int, [C.c_void_p]),
+    "rt_scene_count_visits": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), _P(C.c_float), C.c_int, _P(C.c_uint64), _P(C.c_uint64),
+                                         _P(C.c_float), _P(C.c_uint32)]),
     "rt_intersect_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                      _P(C.c_float), _P(C.c_float), _P(C.c_uint32)]),
     "rt_renderer_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,

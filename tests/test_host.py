@@ -282,3 +282,28 @@ def test_builder_stages_keep_the_tree_valid_and_do_not_raise_its_cost(devlib, sc
     assert cost["1", "greedy"][0] < cost["0", "greedy"][0]
     assert cost["1", "dp"][0] < cost["0", "greedy"][0]
     assert cost["2", "dp"][0] < 1.01 * cost["1", "dp"][0]
+
+
+def test_count_visits_walks_find_the_oracles_hits_and_exact_boxes_visit_no_more(rtlib, oracle, scene_cache):
+    """rt_scene_count_visits (host-only diagnostic): the closest-hit walk of the product tree finds the oracle's hits whichever child boxes it
+    tests — decoded 8-bit planes, exact padded bounds, 10-bit planes — and tighter boxes never visit more nodes."""
+    sd = scene_cache("atrium", detail=1)
+    h, _c = _host_scene(rtlib, sd, abi.RT_BVH_SAH)
+    rng = np.random.default_rng(3)
+    n = 4000
+    org = np.tile(np.asarray(sd.camera.position, np.float32), (n, 1)) + rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    osc = oracle.OracleScene(sd)
+    ot, _ou, _ov, otri = osc.intersect(org, dirs, use_bvh=True)
+    visits = []
+    for mode in (0, 1, 2):
+        v, tt = C.c_uint64(0), C.c_uint64(0)
+        t, tri = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        assert rtlib.rt_scene_count_visits(h, n, abi.fptr(org), abi.fptr(dirs), mode, C.byref(v), C.byref(tt), abi.fptr(t), abi.u32ptr(tri)) == abi.RT_OK, rtlib.rt_last_error()
+        np.testing.assert_array_equal(tri, otri)
+        np.testing.assert_allclose(t[tri != 0xFFFFFFFF], ot[otri != 0xFFFFFFFF], rtol=1e-5)
+        visits.append(v.value)
+        assert tt.value > 0
+    assert visits[1] <= visits[2] <= visits[0] and visits[0] < 1.1 * visits[1]
+    assert rtlib.rt_scene_count_visits(h, n, abi.fptr(org), abi.fptr(dirs), 3, None, None, None, None) == abi.RT_ERR_INVALID
+    rtlib.rt_scene_destroy(h)
