@@ -1,5 +1,5 @@
 // jpeg.cpp — JPEG (ITU-T T.81) decoder for embedded glTF textures: Huffman coding, 8-bit samples, baseline /
-// extended-sequential (SOF0/SOF1) and progressive (SOF2) frames, 1 or 3 components, any sampling factors,
+// extended-sequential (SOF0/SOF1) and progressive (SOF2) frames, 1, 3 or 4 (Adobe CMYK / YCCK) components, any sampling factors,
 // restart intervals. Output is RGBA8, as the reference's loader gets it from
 // stbi_load_from_memory(bytes, size, &w, &h, &comp, 4) (deps/include/tiny_gltf.h:2603-2634 of the reference).
 //
@@ -309,6 +309,10 @@ struct Decoder {
 
     // ---- inverse DCT into an 8x8 block of samples ---------------------------------------------------------------
     static uint8_t clamp8(int x) { return (unsigned)x > 255u ? (x < 0 ? 0 : 255) : (uint8_t)x; }
+    static uint8_t blinn8(int x, int y) { // x * y / 255, rounded (stb_image's stbi__blinn_8x8)
+        const unsigned t = (unsigned)(x * y) + 128u;
+        return (uint8_t)((t + (t >> 8)) >> 8);
+    }
     // 12-bit constants: (int)(c * 4096 + 0.5) on the single-precision constant, truncating — so the negative ones are
     // one step closer to zero than a symmetric rounding would put them (part of the arithmetic being matched)
     static constexpr int fix(float x) { return (int)((double)x * 4096 + 0.5); }
@@ -450,7 +454,7 @@ struct Decoder {
         height = (uint32_t)get16(), width = (uint32_t)get16();
         if (width == 0 || height == 0) bad("empty image");
         ncomp = get8();
-        if (ncomp != 1 && ncomp != 3) bad("only greyscale and three-component images are supported");
+        if (ncomp != 1 && ncomp != 3 && ncomp != 4) bad("bad component count");
         if (len != 8 + 3 * ncomp) bad("bad SOF length");
         for (int i = 0; i < ncomp; ++i) {
             Component& c = comp[i];
@@ -689,7 +693,7 @@ struct Decoder {
             int hs, vs, w_lores, ystep, ypos;
             const uint8_t *line0, *line1;
             std::vector<uint8_t> buf;
-        } up[3];
+        } up[4];
         for (int k = 0; k < ncomp; ++k) {
             Up& r = up[k];
             const Component& c = comp[k];
@@ -702,7 +706,7 @@ struct Decoder {
             r.fn = r.hs == 1 && r.vs == 1 ? up_none : r.hs == 1 && r.vs == 2 ? up_v2 : r.hs == 2 && r.vs == 1 ? up_h2 : r.hs == 2 && r.vs == 2 ? up_hv2 : up_generic;
         }
         const bool is_rgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (app14_transform == 0 && !jfif));
-        const uint8_t* row[3] = {nullptr, nullptr, nullptr};
+        const uint8_t* row[4] = {nullptr, nullptr, nullptr, nullptr};
         for (uint32_t j = 0; j < height; ++j) {
             for (int k = 0; k < ncomp; ++k) {
                 Up& r = up[k];
@@ -719,6 +723,11 @@ struct Decoder {
                 for (uint32_t i = 0; i < width; ++i) out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = row[0][i];
             } else if (is_rgb) {
                 for (uint32_t i = 0; i < width; ++i) out[4 * i] = row[0][i], out[4 * i + 1] = row[1][i], out[4 * i + 2] = row[2][i];
+            } else if (ncomp == 4 && app14_transform == 0) { // Adobe CMYK (stored inverted): channel x K / 255, rounded (stb's blinn_8x8)
+                for (uint32_t i = 0; i < width; ++i) {
+                    const uint8_t m = row[3][i];
+                    out[4 * i] = blinn8(row[0][i], m), out[4 * i + 1] = blinn8(row[1][i], m), out[4 * i + 2] = blinn8(row[2][i], m);
+                }
             } else {
                 auto fixed = [](float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; };
                 const int kr = fixed(1.40200f), kg_r = fixed(0.71414f), kg_b = fixed(0.34414f), kb = fixed(1.77200f);
@@ -730,6 +739,11 @@ struct Decoder {
                     const int b = (yf + cb * kb) >> 20;
                     out[4 * i] = clamp8(r), out[4 * i + 1] = clamp8(g), out[4 * i + 2] = clamp8(b);
                 }
+                if (ncomp == 4 && app14_transform == 2) // Adobe YCCK: the converted channels inverted, times K (a fourth channel under any other
+                    for (uint32_t i = 0; i < width; ++i) { // transform is ignored, as stb ignores it)
+                        const uint8_t m = row[3][i];
+                        out[4 * i] = blinn8(255 - out[4 * i], m), out[4 * i + 1] = blinn8(255 - out[4 * i + 1], m), out[4 * i + 2] = blinn8(255 - out[4 * i + 2], m);
+                    }
             }
         }
     }

@@ -63,51 +63,72 @@ void decode_png_rgba8(const uint8_t* data, size_t size, uint32_t& width, uint32_
         p += 12 + (size_t)len;
     }
     if (!w || !h || w > 16384 || h > 16384) throw std::runtime_error("PNG: bad dimensions");
-    if (interlace) throw std::runtime_error("PNG: interlaced images are not supported");
+    if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
     if (depth != 8 && depth != 16) throw std::runtime_error("PNG: only bit depth 8 or 16 is supported");
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels) throw std::runtime_error("PNG: bad colour type");
     if (ctype == 3 && depth != 8) throw std::runtime_error("PNG: palette images must be 8 bit");
-    const size_t bpp = (size_t)channels * (depth / 8), stride = bpp * w;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    const size_t bpp = (size_t)channels * (depth / 8);
+    // A non-interlaced image is ONE pass over every pixel; an Adam7 image is seven passes, each a reduced image of its own — pixels
+    // (x0 + i * dx, y0 + j * dy) of the full one — with its own filtered scanlines (empty passes have none)
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const int n_pass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int k = 0; k < n_pass; ++k) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        const uint32_t pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (w > ps.x0 && h > ps.y0 && pw && ph) raw_size += (bpp * pw + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
         throw std::runtime_error("PNG: zlib inflate failed");
-    std::vector<uint8_t> cur(stride), prev(stride, 0);
     rgba.assign((size_t)w * h * 4, 255);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* line = raw.data() + (stride + 1) * y;
-        const int filter = line[0];
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
-            switch (filter) {
-            case 0: break;
-            case 1: x += a; break;
-            case 2: x += b; break;
-            case 3: x += (a + b) / 2; break;
-            case 4: x += paeth(a, b, c); break;
-            default: throw std::runtime_error("PNG: bad filter");
+    const uint8_t* line = raw.data();
+    for (int k = 0; k < n_pass; ++k) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        if (!(w > ps.x0 && h > ps.y0)) continue;
+        const uint32_t pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (!pw || !ph) continue;
+        const size_t stride = bpp * pw;
+        std::vector<uint8_t> cur(stride), prev(stride, 0);
+        for (uint32_t py = 0; py < ph; ++py, line += stride + 1) {
+            const int filter = line[0];
+            for (size_t i = 0; i < stride; ++i) {
+                int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
+                switch (filter) {
+                case 0: break;
+                case 1: x += a; break;
+                case 2: x += b; break;
+                case 3: x += (a + b) / 2; break;
+                case 4: x += paeth(a, b, c); break;
+                default: throw std::runtime_error("PNG: bad filter");
+                }
+                cur[i] = (uint8_t)x;
             }
-            cur[i] = (uint8_t)x;
+            const uint32_t y = ps.y0 + py * ps.dy;
+            for (uint32_t px = 0; px < pw; ++px) {
+                const uint32_t xx = ps.x0 + px * ps.dx;
+                const uint8_t* s = cur.data() + bpp * px;
+                uint8_t* d = rgba.data() + ((size_t)y * w + xx) * 4;
+                auto ch = [&](int kk) { return depth == 8 ? s[kk] : s[2 * kk]; }; // 16 bit: high byte
+                switch (ctype) {
+                case 0: d[0] = d[1] = d[2] = ch(0); break;
+                case 2: d[0] = ch(0), d[1] = ch(1), d[2] = ch(2); break;
+                case 3: {
+                    size_t idx = s[0];
+                    if (idx * 3 + 2 < plte.size()) d[0] = plte[idx * 3], d[1] = plte[idx * 3 + 1], d[2] = plte[idx * 3 + 2];
+                    if (idx < trns.size()) d[3] = trns[idx];
+                    break;
+                }
+                case 4: d[0] = d[1] = d[2] = ch(0), d[3] = ch(1); break;
+                case 6: d[0] = ch(0), d[1] = ch(1), d[2] = ch(2), d[3] = ch(3); break;
+                }
+            }
+            prev.swap(cur);
         }
-        for (uint32_t xx = 0; xx < w; ++xx) {
-            const uint8_t* s = cur.data() + bpp * xx;
-            uint8_t* d = rgba.data() + ((size_t)y * w + xx) * 4;
-            auto ch = [&](int k) { return depth == 8 ? s[k] : s[2 * k]; }; // 16 bit: high byte
-            switch (ctype) {
-            case 0: d[0] = d[1] = d[2] = ch(0); break;
-            case 2: d[0] = ch(0), d[1] = ch(1), d[2] = ch(2); break;
-            case 3: {
-                size_t idx = s[0];
-                if (idx * 3 + 2 < plte.size()) d[0] = plte[idx * 3], d[1] = plte[idx * 3 + 1], d[2] = plte[idx * 3 + 2];
-                if (idx < trns.size()) d[3] = trns[idx];
-                break;
-            }
-            case 4: d[0] = d[1] = d[2] = ch(0), d[3] = ch(1); break;
-            case 6: d[0] = ch(0), d[1] = ch(1), d[2] = ch(2), d[3] = ch(3); break;
-            }
-        }
-        prev.swap(cur);
     }
     width = w, height = h;
 }

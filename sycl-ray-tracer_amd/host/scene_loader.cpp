@@ -319,8 +319,18 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
             for (int k = 0; k < 3; ++k) sc.sky[k] = sc.sky[k] * (float)ex.at("sky_strength").num;
     }
 
-    // ---- node hierarchy (Scene::load_node :444-510): local = T * R * S * matrix, global = parents * local ----
+    // ---- node hierarchy (Scene::load_node :444-510, Scene::node_global_matrix :137-146) ----
+    // local = T * R * S * matrix (:18-21). A node's GLOBAL matrix is composed exactly as the reference composes it, from the node UP:
+    //     m = local * scale(global_scale);   for every ancestor, nearest first:  m = ancestor.local * m
+    // (global_scale is the reference's (1, 1, 1) default, :88.) Matrix products do not associate in fp32: composing from the root down —
+    // (root * parent) * local, as rounds 1-4 did — gives other low bits in every transform and normal matrix of a hierarchy three or more deep.
     const Json& nodes = arr("nodes");
+    struct NodeRec {
+        bool loaded = false;
+        int parent = -1;
+        M4 local;
+    };
+    std::vector<NodeRec> recs(nodes.size());
     struct Placed {
         size_t node;
         int mesh;
@@ -328,28 +338,35 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
     };
     std::vector<Placed> placed;
     int cam_node = -1;
-    M4 cam_global = identity();
-    std::function<void(size_t, const M4&, int)> visit = [&](size_t ni, const M4& parent, int depth) {
+    auto global_of = [&](size_t ni) {
+        const float ones[3] = {1.0f, 1.0f, 1.0f};
+        M4 m = mul(recs[ni].local, scale(ones));
+        int depth = 0;
+        for (int p = recs[ni].parent; p >= 0; p = recs[(size_t)p].parent) {
+            if (++depth > 256) throw std::runtime_error("glTF: node hierarchy too deep (cycle?)");
+            m = mul(recs[(size_t)p].local, m);
+        }
+        return m;
+    };
+    std::function<void(size_t, int, int)> visit = [&](size_t ni, int parent, int depth) {
         if (depth > 256) throw std::runtime_error("glTF: node hierarchy too deep (cycle?)");
         const Json& n = nodes.at(ni);
         float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
         if (n.has("translation") && n.at("translation").size() == 3) for (int k = 0; k < 3; ++k) t[k] = (float)n.at("translation").at((size_t)k).num;
         if (n.has("rotation") && n.at("rotation").size() == 4) for (int k = 0; k < 4; ++k) q[k] = (float)n.at("rotation").at((size_t)k).num;
         if (n.has("scale") && n.at("scale").size() == 3) for (int k = 0; k < 3; ++k) s[k] = (float)n.at("scale").at((size_t)k).num;
-        M4 local = mul(mul(translate(t), from_quat(q)), scale(s));
-        if (n.has("matrix") && n.at("matrix").size() == 16) {
-            M4 mm;
+        M4 mm = identity();
+        if (n.has("matrix") && n.at("matrix").size() == 16)
             for (int k = 0; k < 16; ++k) mm.m[k] = (float)n.at("matrix").at((size_t)k).num;
-            local = mul(local, mm);
-        }
-        const M4 global = mul(parent, local);
-        if (n.has("camera")) cam_node = (int)ni, cam_global = global;
+        recs[ni].local = mul(mul(mul(translate(t), from_quat(q)), scale(s)), mm); // ((T * R) * S) * matrix, the identity included (:18-21)
+        recs[ni].parent = parent, recs[ni].loaded = true;
+        if (n.has("camera")) cam_node = (int)ni;
         if (n.has("children"))
-            for (size_t c = 0; c < n.at("children").size(); ++c) visit(n.at("children").at(c).index_value(nodes.size()), global, depth + 1);
-        if (n.has("mesh")) placed.push_back({ni, n.int_or("mesh", 0), global});
+            for (size_t c = 0; c < n.at("children").size(); ++c) visit(n.at("children").at(c).index_value(nodes.size()), (int)ni, depth + 1);
+        if (n.has("mesh")) placed.push_back({ni, n.int_or("mesh", 0), global_of(ni)}); // after the children, with the ancestors' locals already set (:472-492)
     };
     if (scene.has("nodes"))
-        for (size_t r = 0; r < scene.at("nodes").size(); ++r) visit(scene.at("nodes").at(r).index_value(nodes.size()), identity(), 0);
+        for (size_t r = 0; r < scene.at("nodes").size(); ++r) visit(scene.at("nodes").at(r).index_value(nodes.size()), -1, 0);
     // instances attach in NODE INDEX order (src/scene.cpp:101-106), primitives in order
     std::stable_sort(placed.begin(), placed.end(), [](const Placed& a, const Placed& b) { return a.node < b.node; });
     for (const Placed& pl : placed) {
@@ -370,9 +387,33 @@ LoadedScene load_glb(const std::string& path, bool verbose) {
     // camera (Appendix A F6); the two shipped assets get the documented defaults instead. ----
     if (cam_node >= 0) {
         const Json& cn = nodes.at((size_t)cam_node);
-        double fwd[3] = {-(double)cam_global.m[8], -(double)cam_global.m[9], -(double)cam_global.m[10]};
-        const double len = std::sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1] + fwd[2] * fwd[2]);
-        for (int k = 0; k < 3; ++k) sc.camera_direction[k] = (float)(fwd[k] / len), sc.camera_position[k] = cam_global.m[12 + k];
+        // position = the global matrix's translation column; direction = normalize(quat_cast(global) * (0, 0, -1)) (:113-121): the rotation is
+        // taken out of the matrix by GLM's quat_cast (largest-component form), the forward vector is turned by q * v = v + 2 (w (q x v) + q x (q x v))
+        // and normalised as glm::normalize does (v * 1 / sqrt(v . v)). Under scale or shear in the camera's chain this is NOT minus the matrix's
+        // third column normalised (rounds 1-4); glm itself is un-vendored: its published algorithms are restated, in float.
+        const M4 g = global_of((size_t)cam_node);
+        auto M = [&](int c, int r) { return g.m[c * 4 + r]; };
+        const float fx = M(0, 0) - M(1, 1) - M(2, 2), fy = M(1, 1) - M(0, 0) - M(2, 2), fz = M(2, 2) - M(0, 0) - M(1, 1), fw = M(0, 0) + M(1, 1) + M(2, 2);
+        int biggest = 0;
+        float four = fw;
+        if (fx > four) four = fx, biggest = 1;
+        if (fy > four) four = fy, biggest = 2;
+        if (fz > four) four = fz, biggest = 3;
+        const float big = std::sqrt(four + 1.0f) * 0.5f, mult = 0.25f / big;
+        float qw, qx, qy, qz;
+        switch (biggest) {
+        case 0: qw = big, qx = (M(1, 2) - M(2, 1)) * mult, qy = (M(2, 0) - M(0, 2)) * mult, qz = (M(0, 1) - M(1, 0)) * mult; break;
+        case 1: qw = (M(1, 2) - M(2, 1)) * mult, qx = big, qy = (M(0, 1) + M(1, 0)) * mult, qz = (M(2, 0) + M(0, 2)) * mult; break;
+        case 2: qw = (M(2, 0) - M(0, 2)) * mult, qx = (M(0, 1) + M(1, 0)) * mult, qy = big, qz = (M(1, 2) + M(2, 1)) * mult; break;
+        default: qw = (M(0, 1) - M(1, 0)) * mult, qx = (M(2, 0) + M(0, 2)) * mult, qy = (M(1, 2) + M(2, 1)) * mult, qz = big; break;
+        }
+        const float v[3] = {0.0f, 0.0f, -1.0f};
+        const float uv[3] = {qy * v[2] - v[1] * qz, qz * v[0] - v[2] * qx, qx * v[1] - v[0] * qy};           // cross(q.xyz, v)
+        const float uuv[3] = {qy * uv[2] - uv[1] * qz, qz * uv[0] - uv[2] * qx, qx * uv[1] - uv[0] * qy};   // cross(q.xyz, uv)
+        float d[3];
+        for (int k = 0; k < 3; ++k) d[k] = v[k] + ((uv[k] * qw) + uuv[k]) * 2.0f;
+        const float inv = 1.0f / std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        for (int k = 0; k < 3; ++k) sc.camera_direction[k] = d[k] * inv, sc.camera_position[k] = g.m[12 + k];
         const double yfov = js.at("cameras").at((size_t)cn.int_or("camera", 0)).at("perspective").number_or("yfov", 0.8);
         sc.camera_focal_length = (float)(1.0 / std::tan(yfov / 2.0));
         sc.has_camera = true;

@@ -318,6 +318,38 @@ DEFAULT_CAMERAS = {
 }
 
 
+def camera_direction_of(g: np.ndarray):
+    """normalize(quat_cast(global) * (0, 0, -1)) in float32 (src/scene.cpp:113-121): GLM's quat_cast (largest-component form), its
+    q * v = v + 2 (w (q x v) + q x (q x v)) and its normalize (v * 1 / sqrt(v . v)); the same arithmetic as host/scene_loader.cpp."""
+    M = lambda c, r: f32(g[c * 4 + r])
+    fx, fy = f32(f32(M(0, 0) - M(1, 1)) - M(2, 2)), f32(f32(M(1, 1) - M(0, 0)) - M(2, 2))
+    fz, fw = f32(f32(M(2, 2) - M(0, 0)) - M(1, 1)), f32(f32(M(0, 0) + M(1, 1)) + M(2, 2))
+    biggest, four = 0, fw
+    for idx, v in ((1, fx), (2, fy), (3, fz)):
+        if v > four:
+            biggest, four = idx, v
+    big = f32(f32(np.sqrt(f32(four + f32(1)))) * f32(0.5))
+    mult = f32(f32(0.25) / big)
+    sub = lambda a, b: f32(f32(a - b) * mult)
+    add = lambda a, b: f32(f32(a + b) * mult)
+    if biggest == 0:
+        qw, qx, qy, qz = big, sub(M(1, 2), M(2, 1)), sub(M(2, 0), M(0, 2)), sub(M(0, 1), M(1, 0))
+    elif biggest == 1:
+        qw, qx, qy, qz = sub(M(1, 2), M(2, 1)), big, add(M(0, 1), M(1, 0)), add(M(2, 0), M(0, 2))
+    elif biggest == 2:
+        qw, qx, qy, qz = sub(M(2, 0), M(0, 2)), add(M(0, 1), M(1, 0)), big, add(M(1, 2), M(2, 1))
+    else:
+        qw, qx, qy, qz = sub(M(0, 1), M(1, 0)), add(M(2, 0), M(0, 2)), add(M(1, 2), M(2, 1)), big
+    v = (f32(0), f32(0), f32(-1))
+    cross = lambda a, b: (f32(f32(a[1] * b[2]) - f32(b[1] * a[2])), f32(f32(a[2] * b[0]) - f32(b[2] * a[0])), f32(f32(a[0] * b[1]) - f32(b[0] * a[1])))
+    q3 = (qx, qy, qz)
+    uv = cross(q3, v)
+    uuv = cross(q3, uv)
+    d = [f32(v[k] + f32(f32(f32(uv[k] * qw) + uuv[k]) * f32(2))) for k in range(3)]
+    inv = f32(f32(1) / f32(np.sqrt(f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])))))
+    return tuple(float(f32(c * inv)) for c in d)
+
+
 def load_glb(path, name: str | None = None) -> SceneDesc:
     js, blob = read_glb(path)
     name = name or Path(path).stem
@@ -372,37 +404,45 @@ def load_glb(path, name: str | None = None) -> SceneDesc:
         sb.sky = (sb.sky * f32(extras["sky_strength"])).astype(f32)
 
     def local(n) -> np.ndarray:
+        """Node::local_matrix (src/scene.cpp:18-21): ((T * R) * S) * matrix, the identity `matrix` of a TRS node included"""
         m = trs(n.get("translation", (0, 0, 0)), n.get("rotation", (0, 0, 0, 1)), n.get("scale", (1, 1, 1)))
-        if "matrix" in n:
-            m = mat4_mul(m, np.array(n["matrix"], f32))
-        return m
+        return mat4_mul(m, np.array(n["matrix"], f32) if "matrix" in n else mat4_identity())
 
     order = []  # instances are attached in NODE INDEX order (src/scene.cpp:101-106)
     cam = None
+    locals_, parents = {}, {}
 
-    def visit(i, parent_m):
+    def global_of(i) -> np.ndarray:
+        """Scene::node_global_matrix (src/scene.cpp:137-146), composed from the node UP as the reference does — m = local * scale(global_scale), then
+        m = ancestor.local * m for every ancestor, nearest first — not from the root down: fp32 matrix products do not associate."""
+        m = mat4_mul(locals_[i], mat4_scale((1.0, 1.0, 1.0)))
+        p = parents[i]
+        while p is not None:
+            m = mat4_mul(locals_[p], m)
+            p = parents[p]
+        return m
+
+    def visit(i, parent):
         nonlocal cam
         n = nodes[i]
-        g = mat4_mul(parent_m, local(n))
+        locals_[i], parents[i] = local(n), parent
         if "camera" in n:
-            cam = (n, g)
+            cam = i
         for c in n.get("children", []):
-            visit(c, g)
+            visit(c, i)
         if "mesh" in n:
-            order.append((i, n["mesh"], g))
+            order.append((i, n["mesh"], global_of(i)))
 
     for r in scene["nodes"]:
-        visit(r, mat4_identity())
+        visit(r, None)
     for _, mesh_i, g in sorted(order, key=lambda t: t[0]):
         for mesh, mat in meshes[mesh_i]:
             sb.add_instance(mesh, mat, g)
 
     if cam is not None:
-        n, g = cam
-        fwd = np.array([-g[8], -g[9], -g[10]], np.float64)
-        fwd /= np.linalg.norm(fwd)
+        n, g = nodes[cam], global_of(cam)
         yfov = js["cameras"][n["camera"]]["perspective"]["yfov"]
-        sb.camera = CameraPose(tuple(float(v) for v in g[12:15]), tuple(fwd), float(f32(1.0 / math.tan(yfov / 2.0))))
+        sb.camera = CameraPose(tuple(float(v) for v in g[12:15]), camera_direction_of(g), float(f32(1.0 / math.tan(yfov / 2.0))))
     elif name in DEFAULT_CAMERAS:
         sb.camera = DEFAULT_CAMERAS[name]
     return sb.build()

@@ -283,3 +283,56 @@ def test_python_mirror_loads_glb_through_the_cpp_loader(oracle, scene_cache, tmp
     fb, _, rb = oracle.OracleScene(ld).render(cam, 0, 5, 2)
     assert ra == rb
     np.testing.assert_array_equal(fa, fb)
+
+
+def test_node_globals_are_composed_from_the_node_up_and_the_camera_through_a_quaternion(hostlib, tmp_path):
+    """VERDICT r4 item 4. The reference composes a node's global matrix from the node UP (src/scene.cpp:137-146: m = local * scale(global_scale);
+    m = ancestor.local * m, nearest ancestor first) and turns (0, 0, -1) by quat_cast(global) for the camera direction (:113-121). fp32 matrix
+    products do not associate, so a hierarchy three deep with rotations and non-uniform scales tells the two composition orders apart in the low
+    bits: both loaders (C++ and Python) must carry the bottom-up bits, equal to each other, and differ from the top-down product. Under a scaled
+    camera chain the quaternion direction is not minus the matrix's third column."""
+    import struct
+    from rtamd.scenes import camera_direction_of, load_glb, mat4_identity, mat4_mul, mat4_scale, trs
+    blob = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<9f", 0, 0, 1, 0, 0, 1, 0, 0, 1) + struct.pack("<6f", 0, 0, 1, 0, 0, 1) + struct.pack("<3H", 0, 1, 2) + b"\0\0"
+    def quat(axis, angle):
+        a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+        return [float(v) for v in (*(a * np.sin(angle / 2)), np.cos(angle / 2))]
+    nodes = [
+        {"translation": [0.37, -1.21, 2.05], "rotation": quat((0.3, 1.0, 0.2), 0.58), "scale": [1.7, 0.9, 1.3], "children": [1, 4]},
+        {"translation": [-0.61, 0.13, 0.77], "rotation": quat((1.0, 0.1, -0.4), 1.91), "scale": [0.8, 1.1, 2.3], "children": [2]},
+        {"translation": [0.05, 0.5, -0.33], "rotation": quat((-0.2, 0.7, 0.6), 2.63), "scale": [1.9, 0.6, 0.7], "children": [3]},
+        {"translation": [1.3, -0.4, 0.2], "rotation": quat((0.5, -0.5, 0.7), 0.91), "scale": [1.2, 1.2, 0.4], "mesh": 0},
+        {"translation": [0.2, 0.1, -3.0], "rotation": quat((0.1, 0.9, 0.3), 1.27), "scale": [1.0, 2.5, 0.6], "children": [5]},
+        {"translation": [0.0, 0.3, 0.1], "rotation": quat((0.8, 0.2, -0.1), 0.44), "camera": 0},
+    ]
+    d = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob)}],
+         "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 36},
+                         {"buffer": 0, "byteOffset": 72, "byteLength": 24}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+                       {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC2"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+         "materials": [{"pbrMetallicRoughness": {"metallicFactor": 0.0}}], "cameras": [{"type": "perspective", "perspective": {"yfov": 0.7, "znear": 0.1}}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]}],
+         "nodes": nodes, "scenes": [{"nodes": [0]}], "scene": 0}
+    pth = tmp_path / "deep.glb"
+    _craft_glb(pth, d, blob)
+    cs = CppScene(hostlib, pth)
+    py = load_glb(pth, "deep")
+    local = [trs(n.get("translation", (0, 0, 0)), n.get("rotation", (0, 0, 0, 1)), n.get("scale", (1, 1, 1))) for n in nodes]
+    local = [mat4_mul(m, mat4_identity()) for m in local]
+    bottom_up = mat4_mul(local[0], mat4_mul(local[1], mat4_mul(local[2], mat4_mul(local[3], mat4_scale((1, 1, 1))))))
+    top_down = mat4_mul(mat4_mul(mat4_mul(local[0], local[1]), local[2]), local[3])
+    assert (bottom_up.view(np.uint32) != top_down.view(np.uint32)).any(), "the test hierarchy does not tell the two orders apart"
+    got_cpp = np.array(list(cs.instances[0].transform), np.float32)
+    np.testing.assert_array_equal(got_cpp.view(np.uint32), bottom_up.view(np.uint32))
+    np.testing.assert_array_equal(py.transforms[0].view(np.uint32), bottom_up.view(np.uint32))
+    np.testing.assert_array_equal(np.array(list(cs.instances[0].normal_mat), np.float32).view(np.uint32), py.normal_mats[0].view(np.uint32))
+    # the camera: node 5 under the scaled node 4 under the scaled node 0
+    cam_global = mat4_mul(local[0], mat4_mul(local[4], mat4_mul(local[5], mat4_scale((1, 1, 1)))))
+    want_dir = camera_direction_of(cam_global)
+    assert cs.has_camera
+    np.testing.assert_array_equal(np.array(cs.camera.direction, np.float32).view(np.uint32), np.array(want_dir, np.float32).view(np.uint32))
+    np.testing.assert_array_equal(np.array(py.camera.direction, np.float32).view(np.uint32), np.array(want_dir, np.float32).view(np.uint32))
+    np.testing.assert_array_equal(np.array(cs.camera.position, np.float32).view(np.uint32), cam_global[12:15].view(np.uint32))
+    minus_z = -cam_global[8:11].astype(np.float64); minus_z /= np.linalg.norm(minus_z)
+    assert np.abs(np.array(want_dir) - minus_z).max() > 1e-3  # a scaled chain: the rotation the quaternion extracts is not the matrix's third column
+    assert abs(np.linalg.norm(want_dir) - 1.0) < 1e-6

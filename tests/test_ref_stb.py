@@ -147,11 +147,80 @@ def test_undecodable_images_are_errors_in_both(libs):
     ref, host = libs
     for blob in (b"", b"\xff\xd8\xff", b"\xff\xd8\xff\xe0\x00\x10JFIF\x00" + b"\x00" * 64, b"GIF89a" + b"\x00" * 32, b"\x89PNG\r\n\x1a\n" + b"\x00" * 16):
         assert our_decode(host, blob) is None
-    # what this loader does not read but stb does is an error here, never a wrong picture: CMYK JPEG
+
+
+def _adam7_png(img: np.ndarray, depth16: bool = False) -> bytes:
+    """An interlaced (Adam7) PNG of an (h, w, c) uint8 image, c in 1 (grey) / 3 (RGB) / 4 (RGBA), written by hand (PIL writes none): seven
+    reduced images, scanlines with filter types 0-4 in turn (each pass starts over with an all-zero previous line)."""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    bpp = c * (2 if depth16 else 1)
+    raw = bytearray()
+    for k, (x0, y0, dx, dy) in enumerate(((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))):
+        sub = img[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        if depth16:
+            sub = np.stack([sub, (sub.astype(np.int32) * 7 % 256).astype(np.uint8)], -1).reshape(sub.shape[0], sub.shape[1], -1)  # high byte = the picture
+        prev = np.zeros(sub.shape[1] * bpp, np.int32)
+        for j, row in enumerate(sub.reshape(sub.shape[0], -1).astype(np.int32)):
+            f = (j + k) % 5
+            a = np.concatenate([np.zeros(bpp, np.int32), row[:-bpp]])
+            cc = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            if f == 0: pred = 0
+            elif f == 1: pred = a
+            elif f == 2: pred = prev
+            elif f == 3: pred = (a + prev) // 2
+            else:
+                pa, pb, pc = np.abs(prev - cc), np.abs(a - cc), np.abs(a + prev - 2 * cc)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cc))
+            raw.append(f)
+            raw += ((row - pred) % 256).astype(np.uint8).tobytes()
+            prev = row
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    ihdr = struct.pack(">IIBBBBB", w, h, 16 if depth16 else 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 1)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("w,h,c,depth16", [(1, 1, 3, False), (2, 3, 4, False), (5, 7, 1, False), (8, 8, 3, False), (9, 9, 4, False), (33, 17, 3, False),
+                                           (64, 40, 4, False), (13, 21, 3, True), (30, 5, 4, True), (3, 1, 1, False), (1, 6, 3, False)])
+def test_interlaced_png_decodes_like_the_references(libs, w, h, c, depth16):
+    """Adam7-interlaced PNGs (the reference's stb_image reads them, deps/include/stb_image.h:4860-4866; rounds 1-4 refused them):
+    sizes with empty passes, every filter type, grey / RGB / RGBA, 8 and 16 bit — texel for texel what the reference's decoder returns."""
+    ref, host = libs
+    rng = np.random.default_rng(w * 100 + h + c)
+    img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    blob = _adam7_png(img, depth16)
+    a, r = our_decode(host, blob), ref_decode(ref, blob)
+    assert r is not None and r.shape == (h, w, 4)
+    assert a is not None, host.rth_last_error()
+    np.testing.assert_array_equal(a, r)
+    want = np.concatenate([np.repeat(img, 3, -1) if c == 1 else img[..., :3], img[..., 3:4] if c == 4 else np.full((h, w, 1), 255, np.uint8)], -1)
+    np.testing.assert_array_equal(a, want)
+
+
+@pytest.mark.parametrize("transform", [2, 0, 1])
+@pytest.mark.parametrize("opts", [dict(quality=90), dict(quality=75, progressive=True), dict(quality=85, optimize=True)])
+def test_four_component_jpeg_decodes_like_the_references(libs, transform, opts):
+    """Adobe four-component JPEGs (stb_image reads them; rounds 1-4 refused them): plain CMYK as libjpeg writes a CMYK picture
+    (APP14 transform 0), the same data declared YCCK (transform 2) and with an unknown transform (the fourth channel ignored) — every texel
+    what the reference's stb_image returns."""
     from PIL import Image
+    ref, host = libs
+    rng = np.random.default_rng(transform)
+    img = Image.fromarray(_picture(rng, 40, 56), "RGB").convert("CMYK")
     buf = io.BytesIO()
-    Image.new("CMYK", (16, 16), (10, 20, 30, 40)).save(buf, format="JPEG")
-    assert our_decode(host, buf.getvalue()) is None and b"three-component" in host.rth_last_error()
+    img.save(buf, format="JPEG", **opts)
+    blob = bytearray(buf.getvalue())
+    at = blob.find(b"Adobe")
+    assert at > 0 and blob[at + 11] == 0  # APP14: "Adobe", version (2), flags0 (2), flags1 (2), transform
+    blob[at + 11] = transform
+    a, r = our_decode(host, bytes(blob)), ref_decode(ref, bytes(blob))
+    assert r is not None and r.shape == (40, 56, 4)
+    assert a is not None, host.rth_last_error()
+    np.testing.assert_array_equal(a, r)
 
 
 def test_glb_with_jpeg_textures_bakes_the_references_layers(libs, scene_cache, tmp_path):
