@@ -1307,7 +1307,7 @@ def test_deep_traversal_stacks_spill_and_equal_the_oracle(oracle, bvh):
 def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypatch, capfd):
     """RT_KERNEL_STATS=1 selects the STATS instantiations of the traversal kernels (wave-level step counters, scripts/final_profile.sh
     stats): separate kernels compiled from the same source, so they are held to the same frame — megakernel, the wavefront renderer's
-    one-launch schedule and its per-bounce pair — and must print their report."""
+    one-launch schedule, its per-bounce pair, the fused per-bounce kernel and the dynamic-queue instantiation — and must print their report."""
     gs = gpu_scenes("cornell")
     sd = gs.desc
     w, h, depth, spp = 96, 64, 6, 4
@@ -1315,7 +1315,8 @@ def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypa
     monkeypatch.setenv("RT_KERNEL_STATS", "1")
     for cls, kind, sched in [(MegakernelRenderer, abi.RT_RENDERER_MEGAKERNEL, None), (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, None),
                              (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(finish_depth=ALL_BOUNCES, fused_bounce=0)),
-                             (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(finish_depth=ALL_BOUNCES, fused_bounce=1))]:
+                             (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(finish_depth=ALL_BOUNCES, fused_bounce=1)),
+                             (WavefrontRenderer, abi.RT_RENDERER_WAVEFRONT, dict(samples_per_launch=2, requeue=1))]:  # k_wf_finish<STATS, REQ>: the dynamic queue
         f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp)
         r = cls(gs, (w, h), depth, spp)
         if sched:
