@@ -149,7 +149,7 @@ def main() -> int:
         _JSON_FD = os.dup(1)
         os.dup2(2, 1)
     # HIP serves streams from GPU_MAX_HW_QUEUES hardware queues (4 by default): the per-bounce renderers' three lane streams, the frame's stream
-    # and torch's own would share them and run one after the other (rt_mi355x.hip: wf_stream_lanes). Before torch or the library touch HIP:
+    # and torch's own would share them and run one after the other (rt_frame.hip: wf_stream_lanes). Before torch or the library touch HIP:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         return pmc_child(args)

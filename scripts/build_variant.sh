@@ -9,8 +9,8 @@ mkdir -p build
 COMMON="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-parameter"
 HIPF="$COMMON $HIPX --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -mllvm -amdgpu-sched-strategy=${SCHED:-max-ilp} -Wno-unused-result -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $COMMON -x c++ "$@" -c scene_build.cpp -o build/var_${name}_scene.o &
-/opt/rocm/bin/hipcc $HIPF "$@" -c lbvh_gpu.hip -o build/var_${name}_lbvh.o &
-/opt/rocm/bin/hipcc $HIPF "$@" -c rt_mi355x.hip -o build/var_$name.o
+for u in lbvh_gpu rt_abi rt_comm rt_probes; do /opt/rocm/bin/hipcc $HIPF "$@" -c $u.hip -o build/var_${name}_$u.o & done
+/opt/rocm/bin/hipcc $HIPF "$@" -c rt_frame.hip -o build/var_${name}_rt_frame.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/librt_var_$name.so build/var_$name.o build/var_${name}_scene.o build/var_${name}_lbvh.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o build/librt_var_$name.so build/var_${name}_*.o
 echo built build/librt_var_$name.so

@@ -445,7 +445,7 @@ RT_DEV void trav_leaf(const SceneDev& S, Trav& T, const TravStack& stack) {
         static_assert(kMaxLeafTris == 2 && kTriBytes == 40, "the whole-leaf step reads a leaf as 80 contiguous bytes");
         // The two records of a leaf are 80 contiguous bytes: FIVE 16-byte loads instead of 2 x (16 + 16 + 8) — one look-up less in the vector
         // L1 per leaf, the path this kernel loads most — and all five UNCONDITIONAL: a leaf of one record (2 % of the SAH
-        // leaves, every LBVH leaf) reads 40 bytes of its neighbour and ignores them (the buffer ends in 48 bytes of padding, rt_mi355x.hip:
+        // leaves, every LBVH leaf) reads 40 bytes of its neighbour and ignores them (the buffer ends in 48 bytes of padding, rt_abi.hip:
         // rt_scene_create). With the second record's loads under `if (two)` the first test waited for all five at the join and eight
         // v_movs initialised the merged registers: 134.1 instead of 126.5 ms per frame (EXPERIMENTS.md).
         const uint8_t* p4 = S.tris + (size_t)first * kTriBytes;
@@ -752,5 +752,26 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
 // unorm8 image write (saturate, round to nearest even) followed by write_image's (uint8)(c*255)
 // read-back (src/util.hpp:17-22)
 RT_DEV uint8_t to_unorm8(float c) { return (uint8_t)__builtin_rintf(clamp01(c) * 255.0f); }
+
+// LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
+#define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
+    __shared__ u32x4 top_all[4 * kTopNodes]; /* the four planes back to back: trav_inner's fetch addresses them from ONE base */ \
+    u32x4 *const top_w0 = top_all, *const top_w1 = top_all + kTopNodes, *const top_w2 = top_all + 2 * kTopNodes, *const top_ch = top_all + 3 * kTopNodes; \
+    __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
+    int32_t spill[kStackSize - kLdsStack];                                                             \
+    const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
+    top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
+    __syncthreads();                                                                                   \
+    const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
+    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)}; \
+    lds_stack[threadIdx.x] = kTravDone; /* entry 0 of every lane's stack: the sentinel an empty stack pops (rt_device.h: trav_pop_lds) */
+
+// ... and of a kernel that also shades: the head of the scene's normal-matrix and material tables (rt_device.h: ShadeTables). Before
+// RT_TRAVERSAL_LDS, whose barrier covers this fill too.
+#define RT_SHADE_LDS                                                                                   \
+    __shared__ u32x4 shade_nm[3 * kLdsNm], shade_mat[2 * kLdsMats];                                    \
+    shade_tables_fill(S, shade_nm, shade_mat);                                                         \
+    const ShadeTables tab{(lds_u32x4*)shade_nm, (lds_u32x4*)shade_mat, S.lds_nm, S.lds_mats};
+
 
 } // namespace rt

@@ -1,29 +1,12 @@
-// rt_mi355x.hip — implementation of the C ABI in include/rt_mi355x.h on HIP (gfx950).
+// rt_frame.hip — the frames of librt_mi355x.so: tile buffers, schedules, and every launch of a frame (gfx950).
 //
 // Host orchestration of the two renderers. Unlike the reference, which blocks on the host after
 // every kernel (769 blocking submits per 64-spp frame: src/render_wavefront.cpp:396-431), a frame
 // here is ONE asynchronous stream of launches: queue lengths live in device memory, one counter
 // per (sample, depth), so no bounce ever waits for the host.
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h> // types and prototypes only: librccl.so is dlopen()ed by rt_comm_create
-#include <dlfcn.h>
-
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/rt_mi355x.h"
+#include "rt_internal.h"
 #include "rt_kernels.h"
-#include "scene_build.h"
-#include "rt_knobs.h"
 
-using namespace rt;
 
 // Schedule of the wavefront renderer (measured, atrium 1080p 8 spp, Mrays/s): every bounce as its own EXTEND + SHADE launch pair (the
 // reference's schedule) 5103; first 1 / 2 / 3 / 4 / 6 bounces that way, the rest of each path in k_wf_finish 4923 / 4772 / 4942 / 4873 / 5028;
@@ -45,198 +28,7 @@ using namespace rt;
 //  - C > 1, depth first on two stream lanes (RT_WF_REQUEUE=0): 6323 / 6148 / 6012 / 5826 / 5906 Mrays/s for C = 1 / 2 / 4 / 8 / 16 at 1080p
 //    16 spp when waves took private 128-slot chunks (whole pixel-chains: the launch ended with a few waves working through theirs).
 
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,                           \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
-    } while (0)
-
-// nothing may cross the C ABI as a C++ exception (std::vector growth inside the host orchestration can throw)
-template <typename F>
-int no_throw(F&& f) {
-    try {
-        return f();
-    } catch (const std::bad_alloc&) {
-        return fail(RT_ERR_OOM, "host allocation failed");
-    } catch (const std::exception& e) {
-        return fail(RT_ERR_INVALID, std::string("internal error: ") + e.what());
-    }
-}
-
-int device_ok(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available (the render path has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
-    HIPCHK(hipSetDevice(device));
-    return RT_OK;
-}
-
-// device allocation that frees itself on every return path of the C entry points
-struct DevBuf {
-    void* p = nullptr;
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    template <typename T>
-    T* as() const { return static_cast<T*>(p); }
-};
-
-template <typename T>
-int upload(const std::vector<T>& v, const T** out, uint64_t& bytes) {
-    *out = nullptr;
-    const size_t n = std::max<size_t>(v.size(), 1);
-    void* p = nullptr;
-    HIPCHK(hipMalloc(&p, n * sizeof(T)));
-    *out = (const T*)p; // owned by the scene from here on: rt_scene_destroy frees it even if the copy fails
-    bytes += n * sizeof(T);
-    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return RT_OK;
-}
-
-} // namespace
-
-struct rt_scene {
-    HostScene hs;
-    int device = -1;
-    SceneDev dev{};
-    uint64_t device_bytes = 0;
-};
-
-// kernel launches of one frame, in all and per kernel family (rt_stats::launches_by_kernel)
-struct LaunchCount {
-    uint32_t total = 0;
-    uint32_t by[RT_K_COUNT] = {};
-    void add(int kernel, uint32_t n = 1) { total += n, by[kernel] += n; }
-    void also(int kernel, uint32_t n = 1) { by[kernel] += n; } // a second family of a launch already counted
-};
-
-struct rt_renderer {
-    int kind = 0;
-    rt_scene* scene = nullptr;
-    int32_t width = 0, height = 0;
-    uint32_t max_depth = 0, spp = 0, seed_mode = 0;
-    TileDev tile{0, 1, 8, 0};
-    uint32_t n_local = 0; // pixels in this tile
-    bool unusable = false; // the last (re-)allocation of the tile's buffers failed: no frame until one succeeds
-    int n_cus = 256;      // compute units of the device (persistent-kernel grid sizing)
-    hipStream_t stream = nullptr;
-    // outputs (device) used when the caller passes host pointers
-    float* d_f32 = nullptr;
-    uint8_t* d_u8 = nullptr;
-    // megakernel
-    unsigned long long* d_ray_counter = nullptr;
-    u32x4* d_slice_state = nullptr;        // pixel slices (rt_kernels.h: SliceDev): 32 bytes per pixel of the tile, zero when allocated, never cleared
-    MegaFrame* d_frame = nullptr;          // the frame's constants k_megakernel reads from device memory: camera + slices (copied per frame from h_frame, pinned)
-    MegaFrame* h_frame = nullptr;
-    uint32_t slice_tag = 0;                // tag0 of the last frame (grows by kMaxSlices per frame)
-    uint32_t rr_start = 0;                 // Russian roulette from this bounce on (0 = off, the reference's behaviour)
-    unsigned long long* d_stats = nullptr; // RT_KERNEL_STATS=1: wave scheduling statistics (diagnostic)
-    // wavefront: the tile is rendered as K interleaved sub-tiles ("lanes"), each with its own queues and
-    // its own HIP stream. The lanes' launch chains are independent, so the drain tail of one lane's EXTEND
-    // launch and its bandwidth-bound SHADE launch overlap with the other lane's traversal
-    // (measured: 1 lane 3.85, 2 lanes 4.57, 3 lanes 4.63 Grays/s).
-    struct WfLane {
-        TileDev tile{0, 1, 8, 0};
-        uint32_t n_local = 0;
-        QueueDev q[2]{};
-        uint32_t* d_rng = nullptr;
-        float4* d_accum = nullptr;
-        uint32_t* d_counts = nullptr; // spp * (max_depth + 1) queue lengths, then spp * max_depth extend cursors
-        float4* d_hits = nullptr;     // closest-hit record per queue slot
-        // the streaming schedule's dynamic queue (k_wf_finish<.., true>): entries (all ones before every launch) and control words
-        // (tail, head: one 64-byte line each, zeroed before every launch)
-        unsigned long long* d_rq_entries = nullptr;
-        uint32_t* d_rq_ctl = nullptr;
-        uint32_t rq_capacity = 0;
-        // cost ordering of the one-launch schedule (k_wf_tile_cost / k_wf_order_tiles): rays of every pixel's first sample, the 8x8
-        // blocks' keys and their order
-        uint8_t* d_cost = nullptr;
-        uint32_t* d_tile_key = nullptr;
-        uint32_t* d_tile_order = nullptr;
-        uint32_t n_tiles = 0; // 0: no cost ordering for this tile
-        std::vector<uint32_t> h_counts;
-        unsigned long long* d_extra = nullptr; // per launch: rays k_wf_finish traced beyond its queue's length; [spp]: the dynamic queue's error word
-        std::vector<unsigned long long> h_extra;
-        hipStream_t stream = nullptr; // from the device's lane-stream pool (lane_stream_of) unless stream_owned
-        bool stream_owned = false;
-        hipEvent_t ev_done = nullptr;
-        std::vector<hipEvent_t> ev_pool;
-        size_t n_hot = 0;
-        struct Span { uint32_t e0, e1; int kernel; }; // profiling: ev_pool[e0] .. ev_pool[e1] bracket one launch of `kernel`
-        std::vector<Span> spans;
-    };
-    std::vector<WfLane> lanes;
-    hipEvent_t ev_fork = nullptr;
-    // The wavefront frame is a fixed sequence of ~2 * spp * depth dependent launches on the lanes' streams (queue
-    // lengths stay on the device), so it CAN be captured once into a hipGraph and replayed per frame; the camera, the
-    // only per-frame input, is read from d_cam, refreshed by a copy node from the pinned h_cam. Opt-in (RT_WF_GRAPH=1):
-    // on ROCm 7.2 the replayed graph is 1.7x SLOWER than the same launches issued on the two streams (atrium 1080p,
-    // 8 spp: 49.2 ms vs 29.6 ms; the stream launches are already queued far ahead of the device, and the graph's
-    // two branches no longer overlap), so plain launches stay the default.
-    CameraDev* d_cam = nullptr;
-    CameraDev* h_cam = nullptr;
-    // The wavefront renderer's schedule (include/rt_mi355x.h: rt_schedule), set through rt_renderer_set_schedule; the RT_WF_*
-    // environment variables only fill the initial value at rt_renderer_create. What ran is reported in rt_stats.
-    //   finish_depth: bounces rendered launch by launch (EXTEND + SHADE) before k_wf_finish follows the surviving rays to the end of
-    //   their paths; >= max_depth = the reference's schedule (a launch pair per bounce).
-    //   reorder / matsort (f-3): SHADE's compaction bins a block's survivors by (direction octant, 4x4x4 cell of the
-    //   origin) / SHADE partitions a block's rays by material kind before shading them (measured: profiles/r02_reorder.json)
-    rt_schedule sched{0u, 0u, 0u, -1, 0u, 0u, -1, 0u, 0u, -1};
-    // waves per SIMD one k_wf_extend launch asks for; 0 = all 8 on one stream lane, 4 (one 1024-thread workgroup per CU) where lanes overlap: the
-    // lanes' launches then sit side by side instead of queueing workgroups behind each other (3 lanes: 190.4 -> 186.7 ms per frame, 2 lanes 205.0 ->
-    // 199.0; 2 / 6 waves: 201.6 / 190.8). RT_WF_EXTEND_OCC, tuning
-    uint32_t wf_extend_occ = 0;
-    uint32_t wf_finish_occ = 0; // waves per SIMD one k_wf_finish launch asks for; 0 = kMegaWaves / stream lanes (RT_WF_FINISH_OCC, tuning)
-    // SHOOT's input claims (round 3). A device atomic on the queue cursor serialises (~6 ns each, more under contention): with 128-slot
-    // claims a 2 M-ray launch made 16 k of them, and smaller claims were far worse (64 slots: 4.7 -> 3.8 Grays/s, 32: 2.3). Now 85 % of
-    // the queue is handed out STATICALLY in equal parts (whole 64-slot generations per wave) and only the rest goes through the cursor,
-    // in claims of a share of what is left (at most 256 slots, at least the wave's idle lanes or 16) so that no wave starts a long
-    // private chunk when the others are about to leave: 2 / 3 stream lanes 5.20 / 5.28 -> 5.66 / 5.75 Grays/s at 16 spp.
-    uint32_t wf_shoot_chunk = 0; // queue slots per cursor claim at most; 0 = 256 guided, 128 (64 on small tiles) unguided (RT_WF_SHOOT_CHUNK)
-    bool wf_shoot_tail = true;   // guided claims (RT_WF_SHOOT_TAIL=0: a fixed chunk per claim, the first one static, as EXTEND)
-    uint32_t wf_shoot_static_pct = 85; // guided: the share of the queue handed out statically (RT_WF_SHOOT_STATIC_PCT)
-    hipGraphExec_t graph_exec = nullptr;
-    float* graph_f32 = nullptr; // outputs the captured graph writes
-    uint8_t* graph_u8 = nullptr;
-    hipStream_t graph_stream = nullptr;
-    LaunchCount graph_launches{};
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    // rt_frame_gather_begin reads the renderer's tile buffers (d_f32 / d_u8) asynchronously, ordered on the renderer's OWN stream. A next frame
-    // begun on a caller's stream is not ordered behind that: ev_tile_read (recorded on the own stream behind the send / the copies) is what
-    // frame_begin makes such a stream wait for before anything writes the tile again.
-    hipEvent_t ev_tile_read = nullptr;
-    bool tile_read_recorded = false;
-    // the frame between rt_render_frame_begin and rt_render_frame_end
-    bool frame_pending = false;
-    hipStream_t pending_stream = nullptr;
-    rt_stats pending_stats{};
-    size_t pending_hot = 0;
-    std::chrono::high_resolution_clock::time_point pending_t0{};
-    bool profile_kernels = false;
-    std::vector<hipEvent_t> ev_pool;
-    // diagnostics: RT_MEGA_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the number of
-    // resident workgroups per CU without touching the code; RT_MEGA_OCC=<waves per SIMD> sizes the persistent grid to match
-    uint32_t hw_queues = 4; // GPU_MAX_HW_QUEUES as the host had set it when the renderer was created (4 = HIP's default): bounds the automatic stream lanes
-    uint32_t mega_lds_pad = 0, mega_occ = kMegaWaves;
-};
-
-namespace {
+namespace rtlib {
 
 void drop_graph(rt_renderer* r) {
     if (r->graph_exec) (void)hipGraphExecDestroy(r->graph_exec);
@@ -1039,732 +831,4 @@ int render_impl(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d_u
     return rc != RT_OK ? rc : frame_end(r, stats);
 }
 
-} // namespace
-
-extern "C" {
-
-const char* rt_last_error(void) { return g_err.c_str(); }
-int rt_abi_version(void) { return RT_ABI_VERSION; }
-
-int rt_device_count(void) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) return fail(RT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
-    return n;
-}
-
-// Camera::Camera (src/camera.hpp:74-106). Host arithmetic, same operation order as the reference's
-// constructor: normalize, two cross products, viewport (aspect, 1), pixel00, per-pixel deltas.
-int rt_camera_init(rt_camera* out, int32_t width, int32_t height, const float center[3], const float dir_in[3],
-                   float focal_length) {
-    if (!out || !center || !dir_in || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad camera arguments");
-    auto norm = [](const float v[3], float o[3]) {
-        float inv = 1.0f / std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
-        o[0] = v[0] * inv, o[1] = v[1] * inv, o[2] = v[2] * inv;
-    };
-    auto cross = [](const float a[3], const float b[3], float o[3]) {
-        o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0];
-    };
-    float dir[3], right[3], up[3], tmp[3];
-    const float world_up[3] = {0.0f, 1.0f, 0.0f};
-    norm(dir_in, dir);
-    cross(dir, world_up, tmp), norm(tmp, right);
-    cross(right, dir, tmp), norm(tmp, up);
-    const float vp0 = 1.0f * ((float)width / (float)height), vp1 = 1.0f;
-    const float du_div = (float)width / (vp0 * 2.0f), dv_div = (float)height / (vp1 * 2.0f);
-    for (int a = 0; a < 3; ++a) {
-        const float viewport_u = (-right[a]) * vp0, viewport_v = up[a] * vp1;
-        out->center[a] = center[a];
-        out->pixel00[a] = ((center[a] + viewport_u) + viewport_v) + dir[a] * focal_length;
-        out->delta_u[a] = right[a] / du_div;
-        out->delta_v[a] = (-up[a]) / dv_div;
-    }
-    out->width = width, out->height = height;
-    return RT_OK;
-}
-
-int rt_scene_create(const rt_scene_desc* desc, int device, int bvh_kind, rt_scene** out) {
-    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
-    *out = nullptr;
-    if (bvh_kind != RT_BVH_DEFAULT && bvh_kind != RT_BVH_LBVH && bvh_kind != RT_BVH_SAH && bvh_kind != RT_BVH_LBVH_GPU)
-        return fail(RT_ERR_INVALID, "unknown bvh_kind");
-    if (bvh_kind == RT_BVH_LBVH_GPU) { // the build itself runs on the device
-        if (device < 0) return fail(RT_ERR_NO_DEVICE, "RT_BVH_LBVH_GPU needs a device (device >= 0)");
-        int rc0 = device_ok(device);
-        if (rc0 != RT_OK) return rc0;
-    }
-    rt_scene* s = new (std::nothrow) rt_scene();
-    if (!s) return fail(RT_ERR_OOM, "host allocation failed");
-    std::string err;
-    int rc = RT_OK;
-    try {
-        rc = build_host_scene(desc, bvh_kind, s->hs, err);
-    } catch (const std::bad_alloc&) {
-        delete s;
-        return fail(RT_ERR_OOM, "host allocation failed while building the scene");
-    } catch (const std::exception& e) { // nothing may cross the C ABI as an exception
-        delete s;
-        return fail(RT_ERR_INVALID, std::string("scene build failed: ") + e.what());
-    }
-    if (rc != RT_OK) {
-        delete s;
-        return fail(rc, err);
-    }
-    s->device = device;
-    if (device >= 0) {
-        rc = device_ok(device);
-        if (rc == RT_OK) {
-            if (s->hs.nodes.size() > (size_t)(0x7FFFFFFF / 64)) { // (a tree of 33 M nodes: ~130 M triangles)
-                rt_scene_destroy(s);
-                return fail(RT_ERR_INVALID, "BVH too large for 32-bit node offsets");
-            }
-            std::vector<BvhNode> dn(s->hs.nodes);
-            for (BvhNode& n : dn)
-                for (int k = 0; k < 4; ++k)
-                    if (n.child[k] >= 0) n.child[k] *= 64;
-            rc = upload(dn, &s->dev.nodes, s->device_bytes);
-        }
-        if (rc == RT_OK) { // the device's triangle records: the host records' ten live dwords at a kTriBytes stride
-            std::vector<uint8_t> packed(s->hs.tris.size() * (size_t)kTriBytes + 48, 0); // + 48: the whole-leaf step reads 80 bytes at every leaf, also at a last leaf of one record
-            for (size_t i = 0; i < s->hs.tris.size(); ++i) std::memcpy(packed.data() + i * kTriBytes, &s->hs.tris[i], std::min<size_t>(kTriBytes, sizeof(TriRec)));
-            rc = upload(packed, &s->dev.tris, s->device_bytes);
-        }
-        if (rc == RT_OK) rc = upload(s->hs.shade, &s->dev.shade, s->device_bytes);
-        if (rc == RT_OK) rc = upload(s->hs.inst, &s->dev.inst, s->device_bytes);
-        if (rc == RT_OK) rc = upload(s->hs.mats, &s->dev.mats, s->device_bytes);
-        if (rc == RT_OK) rc = upload(s->hs.tex, &s->dev.tex, s->device_bytes);
-        if (rc != RT_OK) {
-            rt_scene_destroy(s);
-            return rc;
-        }
-        s->dev.n_nodes = (uint32_t)s->hs.nodes.size();
-        s->dev.n_tris = (uint32_t)(s->hs.wverts.size() / 9);
-        std::memcpy(s->dev.sky, s->hs.sky, 12);
-        s->dev.packed_mat = s->hs.packed_mat ? 1u : 0u;
-        // what the shading kernels stage in LDS (rt_device.h: ShadeTables): the head of the distinct-matrix table and of the material table
-        const bool stage = s->hs.packed_mat && s->hs.n_layers <= 65536u; // (the staged material keeps its layer in 16 bits)
-        s->dev.lds_nm = stage ? (uint32_t)std::min<size_t>(s->hs.inst.size(), kLdsNm) : 0u;
-        s->dev.lds_mats = stage ? (uint32_t)std::min<size_t>(s->hs.mats.size(), kLdsMats) : 0u;
-        for (int a = 0; a < 3; ++a) {
-            const float ext = s->hs.bounds_hi[a] - s->hs.bounds_lo[a];
-            s->dev.cell_lo[a] = s->hs.bounds_lo[a];
-            s->dev.cell_scale[a] = ext > 0.0f && std::isfinite(ext) ? 4.0f / ext : 0.0f;
-        }
-    }
-    *out = s;
-    return RT_OK;
-}
-
-void rt_scene_destroy(rt_scene* s) {
-    if (!s) return;
-    if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
-        (void)hipFree((void*)s->dev.nodes), (void)hipFree((void*)s->dev.tris), (void)hipFree((void*)s->dev.shade);
-        (void)hipFree((void*)s->dev.inst), (void)hipFree((void*)s->dev.mats), (void)hipFree((void*)s->dev.tex);
-    }
-    delete s;
-}
-
-int rt_scene_info(const rt_scene* s, rt_scene_info_t* out) {
-    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
-    out->n_triangles = (uint32_t)(s->hs.wverts.size() / 9);
-    out->n_nodes = (uint32_t)s->hs.nodes.size();
-    out->max_depth = s->hs.max_depth;
-    out->max_leaf_tris = s->hs.max_leaf_tris;
-    std::memcpy(out->bounds_lo, s->hs.bounds_lo, 12), std::memcpy(out->bounds_hi, s->hs.bounds_hi, 12);
-    out->sah_cost = s->hs.sah_cost;
-    out->device_bytes = s->device_bytes;
-    out->n_leaf_records = (uint32_t)s->hs.tris.size();
-    out->n_split_triangles = s->hs.n_split_triangles;
-    return RT_OK;
-}
-
-int rt_scene_check_bvh(const rt_scene* s) {
-    if (!s) return fail(RT_ERR_INVALID, "null scene");
-    std::string err;
-    int rc = check_bvh(s->hs, err);
-    return rc == RT_OK ? RT_OK : fail(rc, err);
-}
-
-int rt_scene_count_visits(const rt_scene* s, uint32_t n, const float* org, const float* dir, int mode, uint64_t* node_visits, uint64_t* tri_tests,
-                          float* t, uint32_t* tri) {
-    if (!s || (n && (!org || !dir))) return fail(RT_ERR_INVALID, "null argument");
-    std::string err;
-    const int rc = no_throw([&] { return count_visits(s->hs, n, org, dir, mode, node_visits, tri_tests, t, tri, err); });
-    return rc == RT_OK ? RT_OK : fail(rc, err.empty() ? g_err : err);
-}
-
-int rt_intersect_batch(rt_scene* s, uint32_t n, const float* org, const float* dir, float* t, float* u, float* v,
-                       uint32_t* tri) {
-    if (!s || (n && (!org || !dir || !t || !u || !v || !tri))) return fail(RT_ERR_INVALID, "null argument");
-    if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
-    if (n == 0) return RT_OK;
-    for (uint32_t i = 0; i < n; ++i)
-        if (!origin_in_contract_range(s->hs, org + 3 * (size_t)i))
-            return fail(RT_ERR_INVALID, "ray " + std::to_string(i) + ": origin more than 100 scene scales outside the scene's bounds (outside the range of the closest-hit contract)");
-    HIPCHK(hipSetDevice(s->device));
-    DevBuf b_org, b_dir, b_out;
-    HIPCHK(b_org.alloc((size_t)n * 12));
-    HIPCHK(b_dir.alloc((size_t)n * 12));
-    HIPCHK(b_out.alloc((size_t)n * 16));
-    float *d_org = b_org.as<float>(), *d_dir = b_dir.as<float>(), *d_out = b_out.as<float>();
-    HIPCHK(hipMemcpy(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    float* d_t = d_out;
-    float* d_u = d_out + n;
-    float* d_v = d_out + 2 * (size_t)n;
-    uint32_t* d_tri = (uint32_t*)(d_out + 3 * (size_t)n);
-    hipLaunchKernelGGL(k_intersect_batch, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, n, d_org, d_dir, d_t, d_u, d_v, d_tri);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(u, d_u, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(v, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height, uint32_t max_depth,
-                       uint32_t sample_count, uint32_t seed_mode, rt_renderer** out) {
-    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
-    *out = nullptr;
-    if (!scene) return fail(RT_ERR_INVALID, "null scene");
-    if (kind != RT_RENDERER_MEGAKERNEL && kind != RT_RENDERER_WAVEFRONT) return fail(RT_ERR_INVALID, "unknown renderer kind");
-    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(RT_ERR_INVALID, "bad image size");
-    if (sample_count == 0) return fail(RT_ERR_INVALID, "sample_count must be >= 1");
-    if (seed_mode > RT_SEED_MEGAKERNEL) return fail(RT_ERR_INVALID, "unknown seed mode");
-    if ((uint64_t)sample_count * ((uint64_t)max_depth + 1) > (1ull << 26)) return fail(RT_ERR_INVALID, "sample_count * max_depth too large");
-    if (scene->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
-    int rc = device_ok(scene->device);
-    if (rc != RT_OK) return rc;
-    rt_renderer* r = new (std::nothrow) rt_renderer();
-    if (!r) return fail(RT_ERR_OOM, "host allocation failed");
-    r->kind = kind, r->scene = scene, r->width = width, r->height = height;
-    r->max_depth = max_depth, r->spp = sample_count;
-    r->seed_mode = seed_mode != RT_SEED_DEFAULT ? seed_mode
-                   : (kind == RT_RENDERER_MEGAKERNEL ? RT_SEED_MEGAKERNEL : RT_SEED_WAVEFRONT);
-    r->hw_queues = hw_queues_from_env();
-    const char* prof = std::getenv("RT_PROFILE_KERNELS");
-    r->profile_kernels = prof && prof[0] == '1';
-    if (const char* e = dev_knob("RT_MEGA_LDS_PAD")) r->mega_lds_pad = (uint32_t)std::max(0, std::min(100 * 1024, std::atoi(e)));
-    if (const char* e = dev_knob("RT_MEGA_OCC")) r->mega_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
-    auto bail = [&](int code) {
-        rt_renderer_destroy(r);
-        return code;
-    };
-    { // the device's lane-stream pool is set up by the FIRST renderer of either kind (see lane_stream_of: early, and in one burst)
-        hipStream_t s0 = nullptr;
-        bool owned = false;
-        if (lane_stream_of(scene->device, 0, &s0, &owned) != hipSuccess) return bail(fail(RT_ERR_HIP, "cannot create the stream-lane pool"));
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess && prop.multiProcessorCount > 0) r->n_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
-    if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess ||
-        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_tile_read, hipEventDisableTiming) != hipSuccess)
-        return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
-    if (kind == RT_RENDERER_MEGAKERNEL) {
-        if (hipMalloc((void**)&r->d_frame, sizeof(MegaFrame)) != hipSuccess || hipHostMalloc((void**)&r->h_frame, sizeof(MegaFrame)) != hipSuccess)
-            return bail(fail(RT_ERR_OOM, "frame constant buffer allocation failed"));
-    }
-    if (kind == RT_RENDERER_WAVEFRONT) {
-        if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
-            return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
-        // Environment shim for sweep scripts, DEVELOPER builds only (rt_knobs.h; the API is rt_renderer_set_schedule): the variables fill the initial schedule.
-        // RT_WF_STREAMS / RT_WF_REQUEUE alone have always meant "not the one-launch schedule": they imply a launch per sample.
-        rt_schedule& sc = r->sched;
-        if (const char* e = dev_knob("RT_WF_GRAPH")) sc.hip_graph = e[0] == '1';
-        if (const char* e = dev_knob("RT_WF_FINISH_DEPTH")) sc.finish_depth = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = dev_knob("RT_WF_SAMPLES_PER_LAUNCH")) sc.samples_per_launch = (uint32_t)std::max(0, std::atoi(e));
-        if (const char* e = dev_knob("RT_WF_REQUEUE")) sc.requeue = e[0] != '0' ? 1 : 0;
-        if (const char* e = dev_knob("RT_WF_STREAMS")) sc.stream_lanes = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
-        if ((dev_knob("RT_WF_REQUEUE") || dev_knob("RT_WF_STREAMS")) && sc.samples_per_launch == 0) sc.samples_per_launch = 1;
-        if (const char* e = dev_knob("RT_WF_LPT")) sc.cost_order = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : -1); // 2: forced
-        if (const char* e = dev_knob("RT_WF_EXTEND_OCC")) r->wf_extend_occ = (uint32_t)std::max(1, std::min((int)kExtendWaves, std::atoi(e)));
-        if (const char* e = dev_knob("RT_WF_FINISH_OCC")) r->wf_finish_occ = (uint32_t)std::max(1, std::min((int)kMegaWaves, std::atoi(e)));
-        if (const char* e = dev_knob("RT_WF_SHOOT_CHUNK")) r->wf_shoot_chunk = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));
-        if (const char* e = dev_knob("RT_WF_SHOOT_TAIL")) r->wf_shoot_tail = e[0] == '1';
-        if (const char* e = dev_knob("RT_WF_SHOOT_STATIC_PCT")) r->wf_shoot_static_pct = (uint32_t)std::max(0, std::min(100, std::atoi(e)));
-        if (const char* e = dev_knob("RT_WF_REORDER")) sc.reorder = e[0] == '1';
-        if (const char* e = dev_knob("RT_WF_MATSORT")) sc.matsort = e[0] == '1';
-        if (const char* e = dev_knob("RT_WF_FUSED_BOUNCE")) sc.fused_bounce = e[0] == '1';
-    }
-    rc = no_throw([&] { return alloc_tile_buffers(r); });
-    if (rc != RT_OK) return bail(rc);
-    *out = r;
-    return RT_OK;
-}
-
-void rt_renderer_destroy(rt_renderer* r) {
-    if (!r) return;
-    if (r->scene && hipSetDevice(r->scene->device) == hipSuccess) {
-        drain_streams(r, r->pending_stream);
-        free_tile_buffers(r);
-        if (r->d_cam) (void)hipFree(r->d_cam);
-        if (r->h_cam) (void)hipHostFree(r->h_cam);
-        if (r->d_frame) (void)hipFree(r->d_frame);
-        if (r->h_frame) (void)hipHostFree(r->h_frame);
-        for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
-        if (r->ev_begin) (void)hipEventDestroy(r->ev_begin);
-        if (r->ev_end) (void)hipEventDestroy(r->ev_end);
-        if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
-        if (r->ev_tile_read) (void)hipEventDestroy(r->ev_tile_read);
-        if (r->stream) (void)hipStreamDestroy(r->stream);
-    }
-    delete r;
-}
-
-int rt_renderer_set_tile(rt_renderer* r, uint32_t rank, uint32_t world, uint32_t strip_rows) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    if (world == 0 || rank >= world || strip_rows == 0) return fail(RT_ERR_INVALID, "bad tile split");
-    if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
-    HIPCHK(hipSetDevice(r->scene->device));
-    drain_streams(r, r->pending_stream); // the queues are about to be freed: nothing may be running on any of the renderer's streams
-    const TileDev old = r->tile;
-    r->tile.rank = rank, r->tile.world = world, r->tile.strip_rows = strip_rows;
-    const int rc = no_throw([&] { return alloc_tile_buffers(r); });
-    if (rc != RT_OK) r->tile.rank = old.rank, r->tile.world = old.world, r->tile.strip_rows = old.strip_rows;
-    return rc;
-}
-
-int32_t rt_renderer_local_rows(const rt_renderer* r) { return r ? r->tile.local_rows : 0; }
-
-int32_t rt_renderer_global_row(const rt_renderer* r, int32_t local_row) {
-    if (!r || local_row < 0 || local_row >= r->tile.local_rows) return -1;
-    const uint32_t strip = (uint32_t)local_row / r->tile.strip_rows, within = (uint32_t)local_row % r->tile.strip_rows;
-    return (int32_t)((strip * r->tile.world + r->tile.rank) * r->tile.strip_rows + within);
-}
-
-int rt_renderer_set_profiling(rt_renderer* r, int enable) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    r->profile_kernels = enable != 0;
-    return RT_OK;
-}
-
-int rt_renderer_set_russian_roulette(rt_renderer* r, uint32_t start_bounce) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    if (r->rr_start != start_bounce) drop_graph(r); // the bounce flags are baked into the captured launches
-    r->rr_start = start_bounce;
-    return RT_OK;
-}
-
-int rt_renderer_get_schedule(const rt_renderer* r, rt_schedule* out) {
-    if (!r || !out) return fail(RT_ERR_INVALID, "null argument");
-    *out = r->sched;
-    return RT_OK;
-}
-
-int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
-    if (!r || !s) return fail(RT_ERR_INVALID, "null argument");
-    if (s->stream_lanes > 8) return fail(RT_ERR_INVALID, "at most 8 stream lanes");
-    if (s->requeue < -1 || s->requeue > 1 || s->cost_order < -1 || s->cost_order > 1 || s->reorder > 1 || s->matsort > 1 || s->hip_graph > 1 || s->fused_bounce > 1)
-        return fail(RT_ERR_INVALID, "schedule field out of range");
-    if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
-    if (s->pixel_slices < -1 || s->pixel_slices > (int32_t)kMaxSlices) return fail(RT_ERR_INVALID, "pixel_slices: -1 (automatic), 0 or 1 (off), 2 .. 8");
-    if (r->kind != RT_RENDERER_WAVEFRONT && s->pixel_slices == r->sched.pixel_slices) { // the megakernel is one launch: only its pixel slices are a choice
-        r->sched = *s;
-        return RT_OK;
-    }
-    HIPCHK(hipSetDevice(r->scene->device));
-    drain_streams(r, r->pending_stream); // the queues are re-allocated (stream lanes, second queue, hit records, dynamic queue)
-    const rt_schedule old = r->sched;
-    r->sched = *s;
-    const int rc = no_throw([&] { return alloc_tile_buffers(r); });
-    if (rc != RT_OK) r->sched = old; // the buffers are gone (frames are refused), the schedule on record is the last one that worked
-    return rc;
-}
-
-int rt_render_frame(rt_renderer* r, const rt_camera* cam, float* rgba_f32, uint8_t* rgba_u8, rt_stats* stats) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    int rc = no_throw([&] { return render_impl(r, cam, rgba_f32 ? r->d_f32 : nullptr, rgba_u8 ? r->d_u8 : nullptr, r->stream, stats); });
-    if (rc != RT_OK) return rc;
-    if (rgba_f32 && r->n_local) HIPCHK(hipMemcpy(rgba_f32, r->d_f32, (size_t)r->n_local * 16, hipMemcpyDeviceToHost));
-    if (rgba_u8 && r->n_local) HIPCHK(hipMemcpy(rgba_u8, r->d_u8, (size_t)r->n_local * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_render_frame_device(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream,
-                           rt_stats* stats) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    return no_throw([&] { return render_impl(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream, stats); });
-}
-
-int rt_render_frame_begin(rt_renderer* r, const rt_camera* cam, void* d_rgba_f32, void* d_rgba_u8, void* stream) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    return no_throw([&] { return frame_begin(r, cam, (float*)d_rgba_f32, (uint8_t*)d_rgba_u8, stream ? (hipStream_t)stream : r->stream); });
-}
-
-int rt_render_frame_end(rt_renderer* r, rt_stats* stats) {
-    if (!r) return fail(RT_ERR_INVALID, "null renderer");
-    return no_throw([&] { return frame_end(r, stats); });
-}
-
-} // extern "C"
-
-// ---- multi-GPU frame gather: ncclGather of the strip buffers + de-interleave on the root -------------------
-namespace {
-
-struct RcclApi {
-    void* lib = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGather) Gather = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    std::string err; // why the library is unusable: dlerror() read ONCE, right after the failing call (a second dlerror() returns NULL)
-    bool ok() const { return lib && CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString; }
-};
-
-RcclApi& rccl() { // loaded once, on the first rt_comm_create that needs it
-    static RcclApi api = [] {
-        RcclApi a;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (a.lib) break;
-            const char* e = dlerror();
-            a.err = e ? e : "dlopen failed";
-        }
-        if (a.lib) {
-            a.err.clear();
-            auto sym = [&a](const char* name) {
-                void* f = dlsym(a.lib, name);
-                if (!f && a.err.empty()) {
-                    const char* e = dlerror();
-                    a.err = e ? e : (std::string("symbol missing: ") + name);
-                }
-                return f;
-            };
-            a.CommInitAll = (decltype(a.CommInitAll))sym("ncclCommInitAll");
-            a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
-            a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
-            a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
-            a.Gather = (decltype(a.Gather))sym("ncclGather");
-            a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
-        }
-        return a;
-    }();
-    return api;
-}
-
-#define NCCLCHK(expr)                                                                                     \
-    do {                                                                                                  \
-        ncclResult_t r_ = (expr);                                                                         \
-        if (r_ != ncclSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
-    } while (0)
-
-// gathered[rank][row][x] (every rank padded to rows_max rows) -> full[global row][x]; one thread per pixel of the frame
-__global__ void __launch_bounds__(256) k_deinterleave(uint32_t width, uint32_t height, uint32_t world, uint32_t strip_rows, uint32_t rows_max,
-                                                       const float4* __restrict__ g_f32, const uint32_t* __restrict__ g_u8,
-                                                       float4* __restrict__ full_f32, uint32_t* __restrict__ full_u8) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= width * height) return;
-    const uint32_t x = i % width, y = i / width;
-    const uint32_t strip = y / strip_rows, rank = strip % world;
-    const uint32_t local_row = (strip / world) * strip_rows + y % strip_rows; // the inverse of tile_global_row
-    const size_t src = ((size_t)rank * rows_max + local_row) * width + x;
-    if (g_f32) full_f32[i] = g_f32[src];
-    if (g_u8) full_u8[i] = g_u8[src];
-}
-
-} // namespace
-
-struct rt_comm {
-    std::vector<int> devices;
-    std::vector<ncclComm_t> comms; // empty: local mode (a device appears more than once)
-    bool use_rccl = false;
-    // root-device buffers, (re)allocated when the frame geometry changes
-    int32_t width = 0, height = 0;
-    uint32_t rows_max = 0;
-    float4* d_gather_f32 = nullptr;
-    uint32_t* d_gather_u8 = nullptr;
-    float4* d_full_f32 = nullptr;
-    uint32_t* d_full_u8 = nullptr;
-    hipStream_t root_stream = nullptr;
-    // ordering without host waits: ev_tile[i] (on device i) marks "tile i's strips have left / arrived" on renderer i's stream,
-    // ev_frame (root) marks "the de-interleave has read the gather buffer": the next gather's receive waits for it
-    std::vector<hipEvent_t> ev_tile;
-    hipEvent_t ev_frame = nullptr;
-    bool frame_recorded = false;
-    bool gathered_f32 = false, gathered_u8 = false; // planes of the last rt_frame_gather_begin
-    bool broken = false; // a collective failed half-way: the communicators are unusable (rt_comm_destroy + rt_comm_create)
-};
-
-namespace {
-void comm_free_buffers(rt_comm* c) {
-    auto fr = [](auto*& p) {
-        if (p) (void)hipFree((void*)p);
-        p = nullptr;
-    };
-    fr(c->d_gather_f32), fr(c->d_gather_u8), fr(c->d_full_f32), fr(c->d_full_u8);
-}
-} // namespace
-
-extern "C" {
-
-int rt_comm_create(int n, const int* devices, rt_comm** out) {
-    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
-    *out = nullptr;
-    if (n <= 0 || n > 64 || !devices) return fail(RT_ERR_INVALID, "bad device list");
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
-    bool distinct = true;
-    for (int i = 0; i < n; ++i) {
-        if (devices[i] < 0 || devices[i] >= n_dev) return fail(RT_ERR_INVALID, "device index out of range");
-        for (int j = 0; j < i; ++j) distinct = distinct && devices[j] != devices[i];
-    }
-    return no_throw([&] {
-        rt_comm* c = new rt_comm();
-        c->devices.assign(devices, devices + n);
-        auto bail = [&](int code) {
-            rt_comm_destroy(c);
-            return code;
-        };
-        if (hipSetDevice(devices[0]) != hipSuccess || hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming) != hipSuccess)
-            return bail(fail(RT_ERR_HIP, "cannot create a stream on the root device"));
-        c->ev_tile.assign((size_t)n, nullptr);
-        for (int i = 0; i < n; ++i)
-            if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&c->ev_tile[(size_t)i], hipEventDisableTiming) != hipSuccess)
-                return bail(fail(RT_ERR_HIP, "cannot create an event on device " + std::to_string(devices[i])));
-        (void)hipSetDevice(devices[0]);
-        if (distinct) { // one rank per device: RCCL over xGMI
-            if (!rccl().ok()) return bail(fail(RT_ERR_UNSUPPORTED, "librccl.so could not be loaded: " + (rccl().err.empty() ? std::string("symbols missing") : rccl().err)));
-            c->comms.assign((size_t)n, nullptr);
-            const ncclResult_t rc = rccl().CommInitAll(c->comms.data(), n, devices);
-            if (rc != ncclSuccess) {
-                c->comms.clear();
-                return bail(fail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(rc)));
-            }
-            c->use_rccl = true;
-        }
-        *out = c;
-        return (int)RT_OK;
-    });
-}
-
-void rt_comm_destroy(rt_comm* c) {
-    if (!c) return;
-    for (size_t i = 0; i < c->comms.size(); ++i)
-        if (c->comms[i] && hipSetDevice(c->devices[i]) == hipSuccess) (void)rccl().CommDestroy(c->comms[i]);
-    for (size_t i = 0; i < c->ev_tile.size(); ++i)
-        if (c->ev_tile[i] && hipSetDevice(c->devices[i]) == hipSuccess) (void)hipEventDestroy(c->ev_tile[i]);
-    if (!c->devices.empty() && hipSetDevice(c->devices[0]) == hipSuccess) {
-        if (c->root_stream) (void)hipStreamSynchronize(c->root_stream);
-        comm_free_buffers(c);
-        if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
-        if (c->root_stream) (void)hipStreamDestroy(c->root_stream);
-    }
-    delete c;
-}
-
-int rt_comm_uses_rccl(const rt_comm* c) { return c && c->use_rccl ? 1 : 0; }
-const void* rt_comm_frame_f32(const rt_comm* c) { return c ? c->d_full_f32 : nullptr; }
-const void* rt_comm_frame_u8(const rt_comm* c) { return c ? c->d_full_u8 : nullptr; }
-void* rt_renderer_tile_f32(rt_renderer* r) { return r ? r->d_f32 : nullptr; }
-void* rt_renderer_tile_u8(rt_renderer* r) { return r ? r->d_u8 : nullptr; }
-
-// Enqueues the gather of the renderers' last frames and returns at once: nothing in here waits on the host. Order on the device:
-//   renderer i's stream : [frame i rendered] -> (root only: wait ev_frame = the previous de-interleave has read the gather buffer)
-//                         -> ncclGather send (root: + receive) -> record ev_tile[i]
-//   root stream         : wait ev_tile[0] (RCCL: the receive is complete when the root's part of the collective is; device copies:
-//                         wait every ev_tile[i], then the copies) -> k_deinterleave -> record ev_frame
-// A renderer's next frame is enqueued on its own stream behind its send, so the caller may begin the next frame right after this
-// call and collect this one later with rt_comm_wait: the gather overlaps with the next frame's traversal.
-int rt_frame_gather_begin(rt_comm* c, rt_renderer* const* rs, int want_f32, int want_u8) {
-    if (!c || !rs) return fail(RT_ERR_INVALID, "null communicator or renderer list");
-    if (c->broken) return fail(RT_ERR_HIP, "a collective of this communicator failed: destroy it and create a new one");
-    const uint32_t n = (uint32_t)c->devices.size();
-    const bool f32 = want_f32 != 0, u8 = want_u8 != 0;
-    if (!f32 && !u8) return fail(RT_ERR_INVALID, "nothing to gather: ask for the f32 and / or the u8 plane");
-    for (uint32_t i = 0; i < n; ++i) {
-        const rt_renderer* r = rs[i];
-        if (!r) return fail(RT_ERR_INVALID, "null renderer");
-        if (r->frame_pending) return fail(RT_ERR_INVALID, "a renderer still has a frame in flight (rt_render_frame_end first)");
-        if (r->unusable) return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " has no buffers: its last rt_renderer_set_tile / rt_renderer_set_schedule failed (call either again)");
-        if (r->scene->device != c->devices[i]) return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " is not on the communicator's device " + std::to_string(c->devices[i]));
-        if (r->width != rs[0]->width || r->height != rs[0]->height) return fail(RT_ERR_INVALID, "renderers differ in frame size");
-        if (r->tile.world != n || r->tile.rank != i || r->tile.strip_rows != rs[0]->tile.strip_rows)
-            return fail(RT_ERR_INVALID, "renderer " + std::to_string(i) + " is not tile (" + std::to_string(i) + ", " + std::to_string(n) + ") of the frame");
-    }
-    return no_throw([&]() -> int {
-        const int32_t W = rs[0]->width, H = rs[0]->height;
-        const uint32_t strip = rs[0]->tile.strip_rows, rows_max = (uint32_t)rs[0]->tile.local_rows; // rank 0 owns the most rows
-        const size_t tile_px = (size_t)rows_max * (size_t)W, frame_px = (size_t)W * (size_t)H;
-        HIPCHK(hipSetDevice(c->devices[0]));
-        if (c->width != W || c->height != H || c->rows_max != rows_max) {
-            HIPCHK(hipStreamSynchronize(c->root_stream));
-            comm_free_buffers(c);
-            c->width = W, c->height = H, c->rows_max = rows_max;
-            c->frame_recorded = false;
-        }
-        if (f32 && !c->d_full_f32) {
-            HIPCHK(hipMalloc((void**)&c->d_gather_f32, std::max<size_t>(1, tile_px * n) * 16));
-            HIPCHK(hipMalloc((void**)&c->d_full_f32, std::max<size_t>(1, frame_px) * 16));
-        }
-        if (u8 && !c->d_full_u8) {
-            HIPCHK(hipMalloc((void**)&c->d_gather_u8, std::max<size_t>(1, tile_px * n) * 4));
-            HIPCHK(hipMalloc((void**)&c->d_full_u8, std::max<size_t>(1, frame_px) * 4));
-        }
-        c->gathered_f32 = f32, c->gathered_u8 = u8;
-        if (frame_px == 0) return RT_OK;
-        if (c->use_rccl) {
-            // the previous frame's de-interleave must have read the gather buffer before the root receives into it again
-            if (c->frame_recorded) HIPCHK(hipStreamWaitEvent(rs[0]->stream, c->ev_frame, 0));
-            // ONE grouped collective per plane: every rank sends rows_max * W pixels from its own stream (ordered behind its
-            // render), the root receives n blocks. Single-process multi-device RCCL calls must be grouped (rccl.h:213). An error
-            // inside the group is remembered and the group is CLOSED all the same: returning between GroupStart and GroupEnd would
-            // leave this thread's group open and every later collective queued instead of issued.
-            ncclResult_t first = rccl().GroupStart();
-            if (first != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGroupStart: ") + rccl().GetErrorString(first));
-            std::string what;
-            for (uint32_t i = 0; i < n && first == ncclSuccess; ++i) {
-                if (hipSetDevice(c->devices[i]) != hipSuccess) {
-                    first = ncclUnhandledCudaError, what = "hipSetDevice";
-                    break;
-                }
-                if (f32) first = rccl().Gather(rs[i]->d_f32, i == 0 ? (void*)c->d_gather_f32 : nullptr, tile_px * 4, ncclFloat, 0, c->comms[i], rs[i]->stream), what = "ncclGather (f32)";
-                if (u8 && first == ncclSuccess) first = rccl().Gather(rs[i]->d_u8, i == 0 ? (void*)c->d_gather_u8 : nullptr, tile_px * 4, ncclUint8, 0, c->comms[i], rs[i]->stream), what = "ncclGather (u8)";
-            }
-            const ncclResult_t ge = rccl().GroupEnd();
-            (void)hipSetDevice(c->devices[0]);
-            if (first != ncclSuccess || ge != ncclSuccess) {
-                c->broken = true; // part of the collective may be queued on some ranks' streams and never complete
-                return fail(RT_ERR_HIP, (first != ncclSuccess ? what : std::string("ncclGroupEnd")) + ": " + rccl().GetErrorString(first != ncclSuccess ? first : ge) +
-                                            " (the communicator is unusable now: rt_comm_destroy + rt_comm_create)");
-            }
-            HIPCHK(hipEventRecord(c->ev_tile[0], rs[0]->stream)); // the root's receive
-            HIPCHK(hipStreamWaitEvent(c->root_stream, c->ev_tile[0], 0));
-        } else {
-            // the same device more than once (rehearsal): RCCL allows one rank per device, so the blocks move by device copies
-            for (uint32_t i = 0; i < n; ++i) {
-                HIPCHK(hipSetDevice(c->devices[i]));
-                HIPCHK(hipEventRecord(c->ev_tile[i], rs[i]->stream));
-            }
-            HIPCHK(hipSetDevice(c->devices[0]));
-            for (uint32_t i = 0; i < n; ++i) {
-                HIPCHK(hipStreamWaitEvent(c->root_stream, c->ev_tile[i], 0));
-                if (f32) HIPCHK(hipMemcpyAsync(c->d_gather_f32 + tile_px * i, rs[i]->d_f32, tile_px * 16, hipMemcpyDeviceToDevice, c->root_stream));
-                if (u8) HIPCHK(hipMemcpyAsync(c->d_gather_u8 + tile_px * i, rs[i]->d_u8, tile_px * 4, hipMemcpyDeviceToDevice, c->root_stream));
-            }
-        }
-        hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((frame_px + 255) / 256)), dim3(256), 0, c->root_stream, (uint32_t)W, (uint32_t)H, n, strip,
-                           rows_max, f32 ? c->d_gather_f32 : nullptr, u8 ? c->d_gather_u8 : nullptr, c->d_full_f32, c->d_full_u8);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev_frame, c->root_stream));
-        c->frame_recorded = true;
-        // A renderer's next frame must not overwrite its tile before it has been read: RCCL's send sits on the renderer's own stream already;
-        // the device copies read from the root stream, so the own stream is made to wait for them. Either way an event recorded on the own
-        // stream now marks "tile read", and rt_render_frame_begin makes a CALLER's stream wait for it too.
-        for (uint32_t i = 0; i < n; ++i) {
-            HIPCHK(hipSetDevice(c->devices[i]));
-            if (!c->use_rccl) HIPCHK(hipStreamWaitEvent(rs[i]->stream, c->ev_frame, 0));
-            HIPCHK(hipEventRecord(rs[i]->ev_tile_read, rs[i]->stream));
-            rs[i]->tile_read_recorded = true;
-        }
-        HIPCHK(hipSetDevice(c->devices[0]));
-        return RT_OK;
-    });
-}
-
-// Waits for the gather enqueued by rt_frame_gather_begin; copies the frame to the host where a pointer is given.
-int rt_comm_wait(rt_comm* c, float* rgba_f32, uint8_t* rgba_u8) {
-    if (!c) return fail(RT_ERR_INVALID, "null communicator");
-    if ((rgba_f32 && !c->gathered_f32) || (rgba_u8 && !c->gathered_u8)) return fail(RT_ERR_INVALID, "that plane was not gathered");
-    const size_t frame_px = (size_t)c->width * (size_t)c->height;
-    HIPCHK(hipSetDevice(c->devices[0]));
-    if (rgba_f32 && frame_px) HIPCHK(hipMemcpyAsync(rgba_f32, c->d_full_f32, frame_px * 16, hipMemcpyDeviceToHost, c->root_stream));
-    if (rgba_u8 && frame_px) HIPCHK(hipMemcpyAsync(rgba_u8, c->d_full_u8, frame_px * 4, hipMemcpyDeviceToHost, c->root_stream));
-    HIPCHK(hipStreamSynchronize(c->root_stream));
-    return RT_OK;
-}
-
-int rt_frame_gather(rt_comm* c, rt_renderer* const* rs, float* rgba_f32, uint8_t* rgba_u8, int want_device_f32, int want_device_u8) {
-    const int rc = rt_frame_gather_begin(c, rs, rgba_f32 || want_device_f32, rgba_u8 || want_device_u8);
-    return rc != RT_OK ? rc : rt_comm_wait(c, rgba_f32, rgba_u8);
-}
-
-int rt_comm_size(const rt_comm* c) { return c ? (int)c->devices.size() : 0; }
-
-} // extern "C"
-
-extern "C" {
-
-int rt_probe_xorshift(int device, uint32_t seed, uint32_t n, float* out, uint32_t* state_out) {
-    if (!out || !state_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
-    int rc = device_ok(device);
-    if (rc != RT_OK) return rc;
-    DevBuf b_out, b_st;
-    HIPCHK(b_out.alloc((size_t)n * 4));
-    HIPCHK(b_st.alloc(4));
-    hipLaunchKernelGGL(k_probe_xorshift, dim3(1), dim3(64), 0, 0, seed, n, b_out.as<float>(), b_st.as<uint32_t>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, b_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(state_out, b_st.p, 4, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_probe_half_roundtrip(int device, uint32_t n, const float* in, float* out, uint16_t* bits_out) {
-    if (!in || !out || !bits_out || n == 0) return fail(RT_ERR_INVALID, "bad arguments");
-    int rc = device_ok(device);
-    if (rc != RT_OK) return rc;
-    DevBuf b_in, b_out, b_bits;
-    HIPCHK(b_in.alloc((size_t)n * 4));
-    HIPCHK(b_out.alloc((size_t)n * 4));
-    HIPCHK(b_bits.alloc((size_t)n * 2));
-    HIPCHK(hipMemcpy(b_in.p, in, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_half, dim3((n + 255u) / 256u), dim3(256), 0, 0, n, b_in.as<float>(), b_out.as<float>(), b_bits.as<uint16_t>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, b_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(bits_out, b_bits.p, (size_t)n * 2, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_probe_rounding(int device, uint64_t* mismatches) {
-    if (!mismatches) return fail(RT_ERR_INVALID, "bad arguments");
-    int rc = device_ok(device);
-    if (rc != RT_OK) return rc;
-    DevBuf b;
-    HIPCHK(b.alloc(16));
-    HIPCHK(hipMemset(b.p, 0, 16));
-    hipLaunchKernelGGL(k_probe_rounding, dim3(4096), dim3(256), 0, 0, b.as<unsigned long long>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(mismatches, b.p, 16, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_probe_scatter(rt_scene* s, uint32_t material, uint32_t n, const float* dir, const float* normal, const float* uv,
-                     const uint32_t* seed, uint8_t* ok, float* out_dir, float* out_att, uint32_t* seed_out) {
-    if (!s || !dir || !normal || !uv || !seed || !ok || !out_dir || !out_att || !seed_out || n == 0)
-        return fail(RT_ERR_INVALID, "bad arguments");
-    if (s->device < 0) return fail(RT_ERR_NO_DEVICE, "scene was built host-only (device < 0)");
-    if (material >= s->hs.mats.size()) return fail(RT_ERR_INVALID, "material index out of range");
-    HIPCHK(hipSetDevice(s->device));
-    DevBuf b_dir, b_nrm, b_uv, b_od, b_oa, b_seed, b_so, b_ok;
-    HIPCHK(b_dir.alloc((size_t)n * 12));
-    HIPCHK(b_nrm.alloc((size_t)n * 12));
-    HIPCHK(b_uv.alloc((size_t)n * 8));
-    HIPCHK(b_od.alloc((size_t)n * 12));
-    HIPCHK(b_oa.alloc((size_t)n * 12));
-    HIPCHK(b_seed.alloc((size_t)n * 4));
-    HIPCHK(b_so.alloc((size_t)n * 4));
-    HIPCHK(b_ok.alloc((size_t)n));
-    HIPCHK(hipMemcpy(b_dir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b_nrm.p, normal, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b_uv.p, uv, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b_seed.p, seed, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_scatter, dim3((n + 255u) / 256u), dim3(256), 0, 0, s->dev, material, n, b_dir.as<float>(),
-                       b_nrm.as<float>(), b_uv.as<float>(), b_seed.as<uint32_t>(), b_ok.as<uint8_t>(), b_od.as<float>(),
-                       b_oa.as<float>(), b_so.as<uint32_t>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(ok, b_ok.p, (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_dir, b_od.p, (size_t)n * 12, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_att, b_oa.p, (size_t)n * 12, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(seed_out, b_so.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-} // extern "C"
+} // namespace rtlib

@@ -12,21 +12,9 @@
 #include <cstddef>
 
 #include "rt_device.h"
+#include "rt_launch.h"
 
 namespace rt {
-
-// SoA ray queue: 34 bytes per ray in four coalesced planes (the reference's Buffers pads the same
-// state to 44 bytes: src/render_wavefront.hpp:10-38).
-//   org_id : (org.x, org.y, org.z, bits(pixel id))           16 B
-//   a      : halves (dir.x, dir.y, dir.z, att.r)              8 B
-//   b      : halves (att.g, att.b, rad.r, rad.g)              8 B
-//   c      : half   (rad.b)                                   2 B
-struct QueueDev {
-    float4* org_id;
-    uint2* a;
-    uint2* b;
-    uint16_t* c;
-};
 
 RT_DEV void queue_store(const QueueDev& q, uint32_t slot, uint32_t id, const RayState& r) {
     q.org_id[slot] = make_float4(r.org.x, r.org.y, r.org.z, __uint_as_float(id));
@@ -44,26 +32,6 @@ RT_DEV uint32_t queue_load(const QueueDev& q, uint32_t slot, RayState& r) {
     r.rad[0] = (uint16_t)b.y, r.rad[1] = (uint16_t)(b.y >> 16), r.rad[2] = c;
     return __float_as_uint(o.w);
 }
-
-// LDS of a traversal kernel with BLOCK threads: the staged top of the BVH + the per-lane stacks
-#define RT_TRAVERSAL_LDS(BLOCK)                                                                        \
-    __shared__ u32x4 top_all[4 * kTopNodes]; /* the four planes back to back: trav_inner's fetch addresses them from ONE base */ \
-    u32x4 *const top_w0 = top_all, *const top_w1 = top_all + kTopNodes, *const top_w2 = top_all + 2 * kTopNodes, *const top_ch = top_all + 3 * kTopNodes; \
-    __shared__ int32_t lds_stack[kLdsStack * (BLOCK)];                                                 \
-    int32_t spill[kStackSize - kLdsStack];                                                             \
-    const int32_t top_count = (int32_t)S.n_nodes < kTopNodes ? (int32_t)S.n_nodes : kTopNodes;         \
-    top_tree_fill(S, top_w0, top_w1, top_w2, top_ch, top_count);                                       \
-    __syncthreads();                                                                                   \
-    const TopTree top{(lds_u32x4*)top_w0, (lds_u32x4*)top_w1, (lds_u32x4*)top_w2, (lds_u32x4*)top_ch, top_count}; \
-    const TravStack stack{(uint32_t)(size_t)(lds_i32*)(lds_stack + threadIdx.x), spill, 4u * (BLOCK)}; \
-    lds_stack[threadIdx.x] = kTravDone; /* entry 0 of every lane's stack: the sentinel an empty stack pops (rt_device.h: trav_pop_lds) */
-
-// ... and of a kernel that also shades: the head of the scene's normal-matrix and material tables (rt_device.h: ShadeTables). Before
-// RT_TRAVERSAL_LDS, whose barrier covers this fill too.
-#define RT_SHADE_LDS                                                                                   \
-    __shared__ u32x4 shade_nm[3 * kLdsNm], shade_mat[2 * kLdsMats];                                    \
-    shade_tables_fill(S, shade_nm, shade_mat);                                                         \
-    const ShadeTables tab{(lds_u32x4*)shade_nm, (lds_u32x4*)shade_mat, S.lds_nm, S.lds_mats};
 
 RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), h2f(r.dir[2])); }
 
@@ -123,8 +91,6 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #ifndef RT_ROUND_PRIO
 #define RT_ROUND_PRIO 0
 #endif
-constexpr uint32_t kMegaBlock = 512;   // threads per workgroup: 8 independent waves share one LDS copy of the top of the BVH
-constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compiled for (80 VGPRs): 5 -> 4.83, 6 -> 5.05, 8 (spills) -> 3.67 Grays/s
 constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
 constexpr uint32_t kMegaShadePct = 75; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
 constexpr uint32_t kMegaRefill = 1;    // idle lanes that trigger a pixel fetch — as the STARTING value of RefillPolicy:
@@ -157,43 +123,6 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
             w = (t - 1u) << 28;
         }
     }
-};
-// Pixel slices (round 5). A pixel's samples are one sequential chain — its RNG word runs on from sample to sample
-// (src/render_megakernel.cpp:146-153) — and a lane that takes a pixel is busy for ~520 rays, ~20 ms of the 1080p atrium frame: when the
-// cursor reaches the frame's last pixel every lane is somewhere inside such a chain, and the frame's last fifth is a drain in which the
-// machine empties lane by lane (profiles/r04_wave_stats.txt: queue empty after 105.7 of 129.9 ms). The chain has to stay sequential, but
-// not on ONE lane: it is cut into a few SLICES of decreasing length (e.g. 45 + 15 + 4 samples), the cursor hands out all first slices,
-// then all second ones, and so on, and the lane that finishes a slice stores the pixel's state — colour sum and RNG word, 32 bytes —
-// for whichever lane takes the next slice. The frame then drains over the length of the LAST slice. Per pixel the operations and their
-// order are untouched: same RNG sequence, same additions in the same order, bit-identical frame.
-//   state : per pixel of the tile four 8-byte granules {value, tag} — sum r, g, b and the RNG word — written as two write-through (sc1)
-//           16-byte stores and read with two sc1 loads: "the data is the flag" (cdna_hip_programming.md §6, Guideline 16, R2). A reader
-//           takes the state only if ALL FOUR tags say "written for the slice of this frame that starts with sample s" (tag0 + s; tag0
-//           grows by more than spp from frame to frame, the buffer is never cleared): no flag, no fence, no ordering between the stores.
-//   order : slot q of the cursor = slice q / n_slots of pixel slot q % n_slots, so slice j of a pixel is handed out a whole sweep of the
-//           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it
-//           (mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) looks again in its wave's next
-//           shading round. No lane ever waits for a LATER slot: nothing can deadlock.
-//   cuts  : a lane knows its slice by the sample it starts with (taken from bound[] when the slot is claimed) and finds the slice's end
-//           in a 64-bit mask: bit k set = a slice ends before sample k << shift (shift = 0 up to 64 spp).
-constexpr uint32_t kMaxSlices = 8;
-struct SliceDev {
-    u32x4* state;
-    uint32_t tag0;
-    uint32_t shift;
-    unsigned long long cuts;
-    uint32_t bound[kMaxSlices]; // slice j renders samples bound[j - 1] (0 for j = 0) ... bound[j] - 1; bound[n_slices - 1 ...] = spp
-    uint32_t n_slices;          // 1: a lane keeps its pixel for all its samples
-    uint32_t pad;
-};
-// The frame's constants that only a shading round or a refill reads — the camera's twelve floats, the slices — live in DEVICE memory and are
-// loaded where they are used (scalar loads, hot in the scalar cache): as kernel arguments hipcc kept them in ~35 scalar registers through the
-// traversal loop, in a kernel that has none to spare (with the slices on top: 38 scalar registers spilled into vector lanes, 46 vector
-// registers into scratch, 122 -> 145 ms). frame_now() hides the pointer's origin from the compiler, or it would hoist the loads out of the
-// wave's loop again.
-struct MegaFrame {
-    CameraDev cam;
-    SliceDev sl;
 };
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, tag0) == 8 && offsetof(SliceDev, cuts) == 16 && offsetof(SliceDev, bound) == 24, "frame_* below read MegaFrame by byte offset");
@@ -562,10 +491,7 @@ __global__ void __launch_bounds__(1024) k_wf_order_tiles(const uint32_t* __restr
 // (one atomic per chunk), keeps its 64 lanes fed from the chunk, and writes (t, u, v, tri) to hits[slot].
 // Inside the loop only three uniform step kinds exist: inner node, one triangle, or refill
 // (store finished hits + load new rays) when at least kExtendRefill lanes ask for it.
-constexpr uint32_t kExtendChunk = 128;  // queue slots a wave claims per cursor atomic
 constexpr uint32_t kExtendRefill = 16;  // idle lanes that trigger a refill from the wave's chunk
-constexpr uint32_t kExtendBlock = 1024; // 16 independent waves per workgroup
-constexpr uint32_t kExtendWaves = 8;    // waves per SIMD (64 VGPRs): EXTEND is occupancy-sensitive (8 -> 6: -19 %)
 template <bool STATS>
 __global__ void __launch_bounds__(kExtendBlock, kExtendWaves) k_wf_extend(SceneDev S, QueueDev qin, float4* __restrict__ hits,
                                                                     const uint32_t* __restrict__ count_in,
@@ -588,7 +514,7 @@ __global__ void __launch_bounds__(kExtendBlock, kExtendWaves) k_wf_extend(SceneD
     // wave-uniform chunk state. The first chunk is static (chunk index = block index) so that the
     // thousands of waves of a launch do not all start with an atomic on the same word; later chunks
     // come from the cursor, offset by the static ones.
-    // (With 8 waves per SIMD asked for by every launch, the static chunks already cover a 1 M-ray queue: SHOOT's guided claims — rt_mi355x.hip,
+    // (With 8 waves per SIMD asked for by every launch, the static chunks already cover a 1 M-ray queue: SHOOT's guided claims — rt_frame.hip,
     // wf_shoot_tail — were tried here too and LOSE a third, 5.2 -> 3.4 Grays/s on two stream lanes: they turn static chunks into cursor claims.)
     uint32_t chunk_pos = wave_id * kExtendChunk;
     uint32_t chunk_end = chunk_pos + kExtendChunk < n ? chunk_pos + kExtendChunk : n;
@@ -830,15 +756,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev S, QueueDev qin, Queu
 // write-through (`sc1`) stores and read with `sc1` loads, never through a plain load. An entry is ONE 8-byte store and carries its own
 // validity (all ones until written); the accumulator (one 16-byte store) is written when the path ends, the entry after the wave's
 // ticket atomic has returned, and waiting for that return (s_waitcnt vmcnt(0), in-order) retires the accumulator store first.
-struct FinishRequeue {
-    unsigned long long* entries; // P entries, all ones before the launch
-    uint32_t* ctl;               // one 64-byte line each, zero before the launch: [0] tail, [32] head
-    uint32_t* error;             // set when a wave gave up waiting (kRqIdleCap polls with nothing to trace: seconds) — never observed;
-                                 // it turns a logic error into RT_ERR_HIP instead of a hung GPU
-    uint32_t capacity;           // >= P (host-sized)
-};
 constexpr uint32_t kRqIdleCap = 1u << 26;
-constexpr uint32_t kOutBlock = 256u;   // SHOOT: slots of the next queue a workgroup reserves per device atomic
 constexpr uint32_t kNoRay = 0xFFFFFFFFu; // pixel id of a hole in a SHOOT-produced queue
 constexpr uint32_t kRqEmpty = 0xFFFFFFFFu, kRqStage = 96u, kRqFlush = 32u, kRqClaim = 16u;
 static_assert(kRqFlush + 64u <= kRqStage, "a whole wave of new entries must fit behind an unflushed stage");
@@ -1208,68 +1126,6 @@ __global__ void __launch_bounds__(256) k_wf_resolve(uint32_t n_local, uint32_t s
     if (out_u8)
         reinterpret_cast<uint32_t*>(out_u8)[o] = (uint32_t)to_unorm8(c.x) | ((uint32_t)to_unorm8(c.y) << 8) |
                                                  ((uint32_t)to_unorm8(c.z) << 16) | 0xff000000u;
-}
-
-// ---- batch closest-hit query (rt_intersect_batch) and unit probes ------------------------------------
-__global__ void __launch_bounds__(256) k_intersect_batch(SceneDev S, uint32_t n, const float* __restrict__ org,
-                                                          const float* __restrict__ dir, float* __restrict__ t,
-                                                          float* __restrict__ u, float* __restrict__ v,
-                                                          uint32_t* __restrict__ tri) {
-    RT_TRAVERSAL_LDS(256)
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const Hit h = intersect(S, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), stack, top);
-    t[i] = h.t, u[i] = h.u, v[i] = h.v, tri[i] = h.tri;
-}
-
-__global__ void k_probe_xorshift(uint32_t seed, uint32_t n, float* __restrict__ out, uint32_t* __restrict__ state_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t a = seed;
-    for (uint32_t i = 0; i < n; ++i) out[i] = rng_next(a);
-    *state_out = a;
-}
-
-__global__ void __launch_bounds__(256) k_probe_half(uint32_t n, const float* __restrict__ in, float* __restrict__ out,
-                                                     uint16_t* __restrict__ bits) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint16_t h = f2h(in[i]);
-    bits[i] = h;
-    out[i] = h2f(h);
-}
-
-// rcp_rn / inv_sqrt2 (rt_device.h) against the IEEE expressions they stand for, on ALL 2^32 bit patterns: bad[0] / bad[1] count the
-// inputs on which they differ (NaN results compare equal). A wave tests 64 consecutive patterns, the guard ranges are multiples of
-// 2^23: every wave is wholly inside or wholly outside the fast path's range.
-__global__ void __launch_bounds__(256) k_probe_rounding(unsigned long long* __restrict__ bad) {
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nthreads = gridDim.x * 256u;
-    uint32_t b0 = 0, b1 = 0;
-    for (unsigned long long i = tid; i < (1ull << 32); i += nthreads) {
-        const float x = __uint_as_float((uint32_t)i);
-        const float g0 = rcp_rn(x), w0 = 1.0f / x;
-        const float g1 = inv_sqrt2(x), w1 = 1.0f / __builtin_sqrtf(x);
-        if (__float_as_uint(g0) != __float_as_uint(w0) && !(g0 != g0 && w0 != w0)) b0++;
-        if (__float_as_uint(g1) != __float_as_uint(w1) && !(g1 != g1 && w1 != w1)) b1++;
-    }
-    if (b0) atomicAdd(bad + 0, (unsigned long long)b0);
-    if (b1) atomicAdd(bad + 1, (unsigned long long)b1);
-}
-
-__global__ void __launch_bounds__(256) k_probe_scatter(SceneDev S, uint32_t material, uint32_t n,
-                                                        const float* __restrict__ dir, const float* __restrict__ normal,
-                                                        const float* __restrict__ uv, const uint32_t* __restrict__ seed,
-                                                        uint8_t* __restrict__ ok, float* __restrict__ out_dir,
-                                                        float* __restrict__ out_att, uint32_t* __restrict__ seed_out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t st = seed[i];
-    f3 od, oa;
-    const bool r = scatter(S, S.mats[material], st, mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
-                           mk3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]), uv[2 * i], uv[2 * i + 1], od, oa);
-    ok[i] = r ? 1 : 0;
-    out_dir[3 * i] = od.x, out_dir[3 * i + 1] = od.y, out_dir[3 * i + 2] = od.z;
-    out_att[3 * i] = oa.x, out_att[3 * i + 1] = oa.y, out_att[3 * i + 2] = oa.z;
-    seed_out[i] = st;
 }
 
 } // namespace rt

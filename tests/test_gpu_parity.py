@@ -581,7 +581,7 @@ print('RESULT ' + json.dumps(out))
 @pytest.mark.parametrize("env", [{"RT_WF_SHOOT_TAIL": "0"}, {"RT_WF_SHOOT_TAIL": "0", "RT_WF_SHOOT_CHUNK": "32"}, {"RT_WF_SHOOT_STATIC_PCT": "0", "RT_WF_SHOOT_CHUNK": "16"},
                                  {"RT_WF_SHOOT_STATIC_PCT": "100"}, {"RT_WF_SHOOT_STATIC_PCT": "40", "RT_WF_SHOOT_CHUNK": "1024"}, {}])
 def test_shoot_queue_claims_keep_the_frame(dev_scenes, oracle, monkeypatch, env):
-    """SHOOT's input claims (rt_mi355x.hip: wf_shoot_tail): a static share of the queue in equal parts plus guided claims of what is left
+    """SHOOT's input claims (rt_frame.hip: wf_shoot_tail): a static share of the queue in equal parts plus guided claims of what is left
     (the default), fixed chunks (RT_WF_SHOOT_TAIL=0; developer build), the extremes of the static share and of the claim size — which ray a wave traces
     never changes a pixel: frame, unorm8 image and ray count are the oracle's on a frame whose queues are longer than one claim per wave
     and on one that fits a single wave's static part, on one stream lane and on three."""

@@ -34,9 +34,12 @@ def listing(tmp_path_factory):
         elif flags is not None and flags.endswith("-fno-gpu-flush-denormals-to-zero") and "-mllvm" in line:
             flags += " " + line.strip()
     flags = flags.replace("$(COMMON)", common).replace("$(ARCH)", "gfx950")
-    cmd = ["/opt/rocm/bin/hipcc", *flags.split(), "-S", "--cuda-device-only", str(CSRC / "rt_mi355x.hip"), "-o", str(out)]
-    subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
-    return out.read_text().splitlines()
+    lines = []
+    for unit in ("rt_frame.hip", "rt_probes.hip"):  # the two translation units with traversal kernels
+        cmd = ["/opt/rocm/bin/hipcc", *flags.split(), "-S", "--cuda-device-only", str(CSRC / unit), "-o", str(out)]
+        subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
+        lines += out.read_text().splitlines()
+    return lines
 
 
 def _check(lines):
