@@ -1,11 +1,12 @@
-"""Copies the round's evidence from gpurun_out/r04/final (scripts/final_profile.sh) into profiles/r04_*."""
+"""Copies the round's evidence from gpurun_out/r05/final (scripts/final_profile.sh) into profiles/r05_*."""
 import csv, glob, json, os, shutil
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
-F, P, R = REPO / "gpurun_out" / "r04" / "final", REPO / "profiles", "r04_"
+F, P, R = REPO / "gpurun_out" / "r05" / "final", REPO / "profiles", "r05_"
 for src, dst in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("pmc_bench.json", "pmc_bench.json"),
                  ("config_table.txt", "config_table.txt"), ("tile_scaling.txt", "tile_scaling.txt"), ("schedules_64spp.txt", "schedules_64spp.txt"),
-                 ("tile_pmc.txt", "tile_pmc.txt"), ("stats.log", "wave_stats.txt"), ("sah_cost.txt", "sah_cost.txt"), ("stream_pool.txt", "stream_pool.txt")):
+                 ("tile_pmc.txt", "tile_pmc.txt"), ("stats.log", "wave_stats.txt"), ("pixel_slices.txt", "pixel_slices.txt"), ("tile_floor.txt", "tile_floor_final.txt"),
+                 ("shoot_rate.txt", "shoot_rate.txt")):
     if (F / src).exists():
         text = (F / src).read_text()
         if src.endswith(".json") and src != "pmc_bench.json":  # the JSON line only

@@ -1,17 +1,17 @@
 #!/bin/bash
-# Everything committed under profiles/r04_* (GPU box, repo root; outputs under gpurun_out/r04/final, copied into profiles/ by
+# Everything committed under profiles/r05_* (GPU box, repo root; outputs under gpurun_out/r05/final, copied into profiles/ by
 # `python3 scripts/final_profile.sh collect` ... see the end of this file):
 #   1. the default bench line as the driver runs it (bench.py measures traffic + VALU busy itself, child processes under rocprofv3 --pmc)
 #   2. the same command under rocprofv3 --kernel-trace --stats (mean launch duration of the dominant kernels; no PMC, no CPU leg)
 #   3. the wavefront renderer's schedules at 64 spp, BASELINE's configurations, tile scaling (both renderers)
 #   4. counters of the megakernel on 1/8 of the frame against the full frame (what binds the chain regime)
 #   5. wave-level step statistics and frame timelines (RT_KERNEL_STATS=1), one frame and two frames in flight
-#   6. the SAH leaf criterion's traversal weight; the per-bounce pipeline behind other renderers with a process group up (stream pool)
+#   6. pixel slices on 1/N tiles (both renderers), the chain floor (ever smaller tiles), the per-bounce kernel's rate against rays per launch
 # usage: bash scripts/final_profile.sh [part ...]   (parts: bench ktrace tables tilepmc stats misc; default: all)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8
-out=gpurun_out/r04/final; mkdir -p $out
+out=gpurun_out/r05/final; mkdir -p $out
 parts=${@:-bench ktrace tables tilepmc stats misc}
 for part in $parts; do case $part in
 bench)
@@ -23,7 +23,7 @@ ktrace)
 tables)
   python3 scripts/schedule_probe.py 64 > $out/schedules_64spp.txt 2>&1
   python3 scripts/config_table.py > $out/config_table.txt 2>&1
-  python3 scripts/tile_scaling.py 64 "" 1,2,4,8 > $out/tile_scaling.txt 2>&1
+  python3 scripts/tile_scaling.py 64 "" 1,2,4,8 1,2 > $out/tile_scaling.txt 2>&1
   echo tables done ;;
 tilepmc)
   bash scripts/tile_pmc.sh final mega "8 1" > $out/tile_pmc.txt 2>&1
@@ -33,16 +33,9 @@ stats)
   RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
   echo stats done ;;
 misc)
-  for C in 1.0 1.5 1.9 2.5; do
-    echo "== RT_SAH_TRAV_COST=$C"
-    RT_SAH_TRAV_COST=$C RT_KERNEL_STATS=1 python3 scripts/quick_bench.py 16 mega 2>&1 | grep -E "per ray" | tail -1 | cut -c1-300
-    RT_SAH_TRAV_COST=$C python3 scripts/quick_bench.py 16 mega 2>&1 | grep Mrays
-  done > $out/sah_cost.txt 2>&1
-  for FD in 0 1; do
-    echo "== bench.py, all four renderers, RT_BENCH_FORCE_DIST=$FD (1 = a torch process group with RCCL up)"
-    RT_BENCH_FORCE_DIST=$FD python3 bench.py --steps 3 --warmup 1 --no-live-pmc --no-cpu-baseline --no-pipelined 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print({k:(v['value'],v['ms_per_step'],v['roofline'].get('stream_lanes') or v['roofline'].get('pipeline',{}).get('stream_lanes')) for k,v in d['renderers'].items()})"
-  done > $out/stream_pool.txt 2>&1
+  python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 mega > $out/pixel_slices.txt 2>&1
+  python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 wave >> $out/pixel_slices.txt 2>&1
+  python3 scripts/tile_floor.py 64 8,16,32,64 > $out/tile_floor.txt 2>&1
+  python3 scripts/shoot_rate.py > $out/shoot_rate.txt 2>&1
   echo misc done ;;
 esac; done

@@ -197,10 +197,9 @@ int rt_renderer_create(int kind, rt_scene* scene, int32_t width, int32_t height,
     if (hipEventCreate(&r->ev_begin) != hipSuccess || hipEventCreate(&r->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_tile_read, hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
-    if (kind == RT_RENDERER_MEGAKERNEL) {
-        if (hipMalloc((void**)&r->d_frame, sizeof(MegaFrame)) != hipSuccess || hipHostMalloc((void**)&r->h_frame, sizeof(MegaFrame)) != hipSuccess)
-            return bail(fail(RT_ERR_OOM, "frame constant buffer allocation failed"));
-    }
+    // (the megakernel's camera and slices; the wavefront renderer's one-launch schedule uses the slices part)
+    if (hipMalloc((void**)&r->d_frame, sizeof(MegaFrame)) != hipSuccess || hipHostMalloc((void**)&r->h_frame, sizeof(MegaFrame)) != hipSuccess)
+        return bail(fail(RT_ERR_OOM, "frame constant buffer allocation failed"));
     if (kind == RT_RENDERER_WAVEFRONT) {
         if (hipMalloc((void**)&r->d_cam, sizeof(CameraDev)) != hipSuccess || hipHostMalloc((void**)&r->h_cam, sizeof(CameraDev)) != hipSuccess)
             return bail(fail(RT_ERR_OOM, "camera buffer allocation failed"));
@@ -295,7 +294,7 @@ int rt_renderer_set_schedule(rt_renderer* r, const rt_schedule* s) {
         return fail(RT_ERR_INVALID, "schedule field out of range");
     if (r->frame_pending) return fail(RT_ERR_INVALID, "a frame is in flight (rt_render_frame_end first)");
     if (s->pixel_slices < -1 || s->pixel_slices > (int32_t)kMaxSlices) return fail(RT_ERR_INVALID, "pixel_slices: -1 (automatic), 0 or 1 (off), 2 .. 8");
-    if (r->kind != RT_RENDERER_WAVEFRONT && s->pixel_slices == r->sched.pixel_slices) { // the megakernel is one launch: only its pixel slices are a choice
+    if (r->kind != RT_RENDERER_WAVEFRONT && (s->pixel_slices > 1 || s->pixel_slices < 0) == (r->sched.pixel_slices > 1 || r->sched.pixel_slices < 0)) { // the megakernel is one launch: only its pixel slices are a choice (their state buffer exists or not)
         r->sched = *s;
         return RT_OK;
     }

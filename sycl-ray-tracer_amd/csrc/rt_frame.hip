@@ -130,6 +130,10 @@ bool wf_uses_requeue(const rt_renderer* r) { return r->sched.requeue != 0 && !wf
 bool wf_cost_order(const rt_renderer* r) {
     if (r->sched.cost_order == 0 || !wf_one_launch(r) || wf_stream_lanes(r) != 1) return false;
     if (r->sched.cost_order > 0) return true;
+    // automatic: pixel slices (round 5) do more for the same tiles — half the 1080p frame 59 ms against 69 with the cost-ordered second launch —
+    // so the cost order is left to tiles that are not sliced
+    const bool sliced = r->sched.pixel_slices > 1 || (r->sched.pixel_slices < 0 && (double)r->n_local > 1.25 * r->n_cus * 4.0 * kMegaWaves * 64.0 && r->spp >= 2);
+    if (sliced && !r->sched.hip_graph) return false;
     return !wf_spread(r) && r->spp >= 32 && (uint64_t)r->n_local <= 4ull * r->n_cus * 4u * kMegaWaves * 64u;
 }
 
@@ -264,6 +268,14 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
             // (a frame captured into a hipGraph forks into its lanes' streams and puts them into capture mode: such a renderer gets lane
             // streams of its OWN — on the device's shared pool another renderer's launches would be captured into this graph, or fail)
             HIPCHK(lane_stream_of(r->scene->device, r->sched.hip_graph && K > 1 ? kLanePool + k : k, &L.stream, &L.stream_owned));
+            if (K == 1 && wf_one_launch(r) && !r->sched.hip_graph && r->sched.pixel_slices != 0 && r->sched.pixel_slices != 1 && (uint64_t)m * 32u < (1ull << 31)) {
+                // pixel slices of the one-launch schedule (k_wf_finish<.., SLICED>): the state that changes lanes, 32 bytes per pixel (a replayed
+                // hipGraph would replay the frame's tags too: no slices there)
+                HIPCHK(dalloc((void**)&r->d_slice_state, m * 32));
+                HIPCHK(hipMemsetAsync(r->d_slice_state, 0, m * 32, r->stream));
+                HIPCHK(hipStreamSynchronize(r->stream));
+                r->slice_tag = 0;
+            }
             HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         }
     }
@@ -290,7 +302,7 @@ int alloc_tile_buffers(rt_renderer* r) {
 // over its LAST slice (about 1/16 of the samples), instead of over a whole pixel.
 //   G <= 1.25 : one slice — nothing is handed out after the first generation, a slice would only wait for the one before it
 //   forced    : rt_schedule::pixel_slices >= 2 slices of that geometry whatever G is (tests, sweeps)
-SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint32_t tag0) {
+SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint32_t tag0) { // grid: workgroups of kMegaBlock threads the launch keeps resident
     SliceDev sl{};
     sl.state = r->d_slice_state, sl.n_slices = 1, sl.tag0 = tag0;
     for (uint32_t k = 0; k < kMaxSlices; ++k) sl.bound[k] = r->spp;
@@ -547,20 +559,36 @@ int enqueue_wavefront(rt_renderer* r, float* d_f32, uint8_t* d_u8, hipStream_t s
                 // rays that are not a queue's length (every bounce beyond D0, every ray of the samples generated in-lane) are counted here
                 unsigned long long* extra = L.d_extra + s;
                 const bool req = n_samples > 1 && L.d_rq_entries != nullptr;
+                // pixel slices: the one-launch schedule on one lane, outside a graph capture and the cost-ordered pair of launches
+                SliceDev sl{};
+                sl.n_slices = 1;
+                if (K == 1 && r->d_slice_state && !capturing && !lpt && n_samples == r->spp && D0 == 0 && !shoot_frame) {
+                    if (r->slice_tag > 0xFFFFFFFFu - 2u * (r->spp + 1u)) {
+                        HIPCHK(hipMemsetAsync(r->d_slice_state, 0, (size_t)L.n_local * 32, ls));
+                        r->slice_tag = 0;
+                    }
+                    r->slice_tag += r->spp + 1u;
+                    sl = mega_slices(r, fin_grid, L.n_local, r->slice_tag);
+                    r->h_frame->cam = *r->h_cam, r->h_frame->sl = sl;
+                    HIPCHK(hipMemcpyAsync(r->d_frame, r->h_frame, sizeof(MegaFrame), hipMemcpyHostToDevice, ls));
+                }
+                r->last_slices = sl.n_slices;
                 FinishRequeue fq{L.d_rq_entries, L.d_rq_ctl, reinterpret_cast<uint32_t*>(L.d_extra + r->spp), L.rq_capacity};
                 if (req) { // the launch's dynamic queue: all entries invalid, counters zero
                     if (int rc_ = fill_bytes(L.d_rq_entries, 0xFF, (size_t)L.n_local * (n_samples - 1u) * 8, ls, capturing)) return rc_;
                     if (int rc_ = fill_bytes(L.d_rq_ctl, 0, 80 * 4, ls, capturing)) return rc_;
                 }
-#define RT_FINISH_LAUNCH(ST, RQ)                                                                                                              \
-    hipLaunchKernelGGL((k_wf_finish<ST, RQ>), dim3(fin_grid), dim3(kMegaBlock), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0,        \
+#define RT_FINISH_LAUNCH(ST, RQ, SL)                                                                                                          \
+    hipLaunchKernelGGL((k_wf_finish<ST, RQ, false, SL>), dim3(fin_grid), dim3(kMegaBlock), 0, ls, S, r->d_cam, L.tile, L.q[buf[k]], counts + D0, \
                        cursors + (size_t)s * D + D0, L.d_rng, L.d_accum, extra, D0, D, n_samples, r->rr_start,                                 \
                        ST ? r->d_stats : (unsigned long long*)nullptr, fq, chunk_slots, lpt && s == 0 ? L.d_cost : (uint8_t*)nullptr, QueueDev{}, (uint32_t*)nullptr, 0u,     \
-                       shoot_frame ? 1u : 0u)
-                if (r->d_stats && req) RT_FINISH_LAUNCH(true, true);
-                else if (r->d_stats) RT_FINISH_LAUNCH(true, false);
-                else if (req) RT_FINISH_LAUNCH(false, true);
-                else RT_FINISH_LAUNCH(false, false);
+                       shoot_frame ? 1u : 0u, r->d_frame, sl.n_slices)
+                if (sl.n_slices > 1u && r->d_stats) RT_FINISH_LAUNCH(true, false, true);
+                else if (sl.n_slices > 1u) RT_FINISH_LAUNCH(false, false, true);
+                else if (r->d_stats && req) RT_FINISH_LAUNCH(true, true, false);
+                else if (r->d_stats) RT_FINISH_LAUNCH(true, false, false);
+                else if (req) RT_FINISH_LAUNCH(false, true, false);
+                else RT_FINISH_LAUNCH(false, false, false);
 #undef RT_FINISH_LAUNCH
                 if (r->profile_kernels) {
                     HIPCHK(hipEventRecord(e1, ls));
@@ -693,6 +721,7 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                 if (L.n_local) chunk = std::min(chunk, wf_chunk(r, L.n_local));
             stats->samples_per_launch = chunk;
             stats->cost_ordered = launches.by[RT_K_WF_TILE_ORDER] ? 1u : 0u;
+            stats->pixel_slices = r->last_slices;
         }
     }
     if (stats) {

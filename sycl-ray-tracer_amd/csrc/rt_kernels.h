@@ -768,7 +768,14 @@ RT_DEV void rq_store64(unsigned long long* p, unsigned long long v) { __hip_atom
 // and shading round) with the pixel's RNG word stored back, exactly what the reference's shoot_rays does per bounce
 // (src/render_wavefront.cpp:244-312: intersect, shade, compact, one kernel). With bounce_limit = 1 this is the reference's schedule as
 // ONE launch per bounce: no hit-record round trip (EXTEND -> SHADE costs 32 B per ray) and half the launches of the split pipeline.
-template <bool STATS, bool REQ, bool LIMIT = false>
+// SLICED (k_wf_finish<.., false, false, true>; one launch per frame only): the pixel slices of k_megakernel (above) in the queue-fed loop — slot q of the
+// cursor = slice q / n of queue slot q % n; a lane knows its slice by the sample it starts with; the state that changes lanes is the RNG
+// word and the pixel's three clamped sums, as four {value, tag} granules in `slices->sl.state`. Within a slice the sums live in LDS (as in
+// k_megakernel), NOT in the accumulator in memory: two lanes on different XCDs adding to accum[id] one after the other with plain accesses
+// leave the same bytes dirty in two L2s that do not know of each other (seen: a frame off in its last bits with eight slices). The
+// accumulator is written once, by the lane that finishes the pixel. The LDS for the sums is what the unsliced kernel spends on the cached
+// pixel coordinates (xg_lds): a sliced launch divides for them per sample.
+template <bool STATS, bool REQ, bool LIMIT = false, bool SLICED = false>
 __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S, const CameraDev* __restrict__ camp, TileDev tile, QueueDev qin,
                                                                     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ cursor,
                                                                     uint32_t* __restrict__ rng_buf, float4* __restrict__ accum,
@@ -776,8 +783,10 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                                                                     uint32_t n_samples, uint32_t rr_start,
                                                                     unsigned long long* __restrict__ stats_out, FinishRequeue fq, uint32_t chunk_slots, uint8_t* __restrict__ cost_out,
                                                                     QueueDev qout = QueueDev{}, uint32_t* __restrict__ count_out = nullptr, uint32_t bounce_limit = 0,
-                                                                    uint32_t qflags = 0) {
+                                                                    uint32_t qflags = 0, const MegaFrame* slices = nullptr, uint32_t n_slices = 1) {
     static_assert(!(REQ && LIMIT), "the dynamic queue and the per-bounce hand-over are different schedules");
+    static_assert(!(SLICED && (REQ || LIMIT)), "pixel slices belong to the one-launch schedule");
+    constexpr uint32_t kPend = 0x40000000u; // SLICED, in `depth`: the lane has taken a later slice of a pixel and waits for its state (as in k_megakernel)
     // qflags & 1 (every launch of a frame whose bounces are SHOOT launches): the input queue may hold HOLES (entries whose pixel id is
     // kNoRay: the unused tail of a workgroup's last output block, below) and is therefore longer than the number of rays in it, so every
     // traced ray is counted here, on the device, instead of by the host as a queue length.
@@ -810,10 +819,15 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     // global row were four integer divisions per SAMPLE (id % width, id / width, and the two of tile_global_row: ~100 instructions of a
     // ~600-instruction shading round that nearly always holds a lane starting a sample); they are now taken once per PIXEL and kept,
     // packed, in one LDS word per lane (images of up to 65,535 x 65,535; larger ones divide as before).
-    __shared__ uint32_t xg_lds[kMegaBlock];
+    __shared__ uint32_t xg_lds[SLICED ? 1u : kMegaBlock];
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-    lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + threadIdx.x;
-    const bool xg_packed = camp->width < 65536 && camp->height < 65536;
+    lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + (SLICED ? 0u : threadIdx.x);
+    const bool xg_packed = !SLICED && camp->width < 65536 && camp->height < 65536;
+    __shared__ float sum_lds[SLICED ? 3u * kMegaBlock : 1u]; // SLICED: the pixel's three sums while this lane holds it
+    typedef __attribute__((address_space(3))) float lds_f32_t;
+    lds_f32_t* const sum_r = (lds_f32_t*)sum_lds + (SLICED ? threadIdx.x : 0u);
+    lds_f32_t* const sum_g = sum_r + (SLICED ? kMegaBlock : 0u);
+    lds_f32_t* const sum_b = sum_g + (SLICED ? kMegaBlock : 0u);
     bool chunk_dq = false; // REQ: the wave's current chunk is a range of POSITIONS of the dynamic queue
     bool drained = false;  // REQ: the dynamic queue has no position left (wave-uniform)
     // REQ: this lane holds a position of the dynamic queue and polls it. A waiting lane has no pixel, so its position lives in `id` and
@@ -842,9 +856,14 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     }
     uint32_t seen = n_waves * first_slots;                                    // the cursor as this wave last saw it (+ the static chunks)
     const uint32_t inv_waves = tail_guided ? 0x10000u / (n_waves ? n_waves : 1u) + 1u : 0u; // share = left * inv_waves >> 16 (rounded up a little)
+    const uint32_t n_total = SLICED ? n * n_slices : n; // slots of the cursor: every slice of every queue slot
+    uint32_t slice_j = 0;                               // SLICED, wave-uniform: the slice the wave's current chunk starts in
     uint32_t chunk_pos = wave_id * first_slots; // first chunk static, later ones from the cursor (as EXTEND)
-    uint32_t chunk_end = chunk_pos + first_slots < n ? chunk_pos + first_slots : n;
-    bool exhausted = chunk_pos >= n; // the sample-0 queue has no chunk left for this wave
+    uint32_t chunk_end = chunk_pos + first_slots < n_total ? chunk_pos + first_slots : n_total;
+    bool exhausted = chunk_pos >= n_total; // the sample-0 queue has no chunk left for this wave
+    auto state_rsrc = [&](const SliceNow& sn) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)sn.head.y << 32) | sn.head.x), 0, (int)(n * 32u), 0x00020000);
+    };
     auto leave = [&]() { // SHOOT: the workgroup's last wave to exit marks the unused tail of the workgroup's output block
         if (!LIMIT) return;
         uint32_t order = 0;
@@ -905,11 +924,11 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                         if (lane == 0) base = atomicAdd(cursor, w);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + n_waves * first_slots;
                         seen = base + w;
-                        if (base >= n) {
+                        if (base >= n_total) {
                             exhausted = true;
                         } else {
                             chunk_pos = base;
-                            chunk_end = base + w < n ? base + w : n;
+                            chunk_end = base + w < n_total ? base + w : n_total;
                         }
                     }
                     if (REQ && exhausted) { // positions of the dynamic queue, whether their entries exist yet or not
@@ -930,16 +949,33 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                     const uint32_t avail = chunk_end - chunk_pos;
                     const uint32_t take = cnt < avail ? cnt : avail;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                    uint32_t first_here = 0, first_next = 0, slice_base = 0; // SLICED: first samples of the slice the chunk starts in and of the next, that slice's first slot
+                    if (SLICED) {
+                        while (slice_j + 1u < n_slices && chunk_pos >= (slice_j + 1u) * n) slice_j++; // (chunks only move forward)
+                        slice_base = slice_j * n;
+                        if (slice_j) first_here = frame_slice_bound(slices, slice_j - 1u);
+                        first_next = frame_slice_bound(slices, slice_j);
+                    }
                     if (!live && !waiting && rank < take) {
                         if (REQ && chunk_dq) {
                             id = chunk_pos + rank; // the lane's position
                             waiting = true;
                         } else {
-                            id = queue_load(qin, chunk_pos + rank, r);
-                            if (!(holes && id == kNoRay)) { // (a hole: the slot is consumed, the lane stays idle until the next refill)
+                            uint32_t slot = chunk_pos + rank, first = 0; // `first`: the sample the lane's slice starts with
+                            if (SLICED) {
+                                const bool next = slot - slice_base >= n; // (a claim of at most 64 slots crosses at most one slice boundary)
+                                slot = next ? slot - slice_base - n : slot - slice_base, first = next ? first_next : first_here;
+                            }
+                            id = queue_load(qin, slot, r);
+                            if (SLICED && first != 0u) { // a later slice: the ray in the queue is sample 0's; the pixel's state comes from the lane that renders the slice before (below)
+                                depth = kPend;
+                                samples_left = n_samples - first, first_counted = false;
+                                live = true;
+                            } else if (!(holes && id == kNoRay)) { // (a hole: the slot is consumed, the lane stays idle until the next refill)
                                 rng = rng_buf[id]; // ScopedRng load (src/render_wavefront.cpp:15-32): held in a register until the lane lets the pixel go
                                 depth = first_depth;
                                 samples_left = n_samples, first_counted = !holes;
+                                if (SLICED) *sum_r = 0.0f, *sum_g = 0.0f, *sum_b = 0.0f; // (k_wf_init left the accumulator at zero)
                                 if (!REQ && n_samples > 1u && xg_packed) { // the pixel's coordinates for its later camera rays: two divisions ONCE per pixel
                                     const uint32_t w = (uint32_t)camp->width;
                                     *xg_p = (id % w) | ((uint32_t)tile_global_row(tile, (int)(id / w)) << 16);
@@ -991,13 +1027,36 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         __builtin_amdgcn_s_setprio(0);
         bool requeue = false, slot_finished = false, hand_on = false;
         // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes): every other ray counts here
-        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth)));
-        if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
+        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
+        if (SLICED && live && T.cur == kTravDone && depth >= kPend) { // a lane that waits for its pixel's state: four {value, tag} granules, taken when all carry this slice's tag
+            const SliceNow sn = frame_slices(slices);
+            const auto rsrc = state_rsrc(sn);
+            const uint32_t at = id * 32u, tag = sn.head.z + (n_samples - samples_left);
+            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
+            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
+            if (w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) {
+                *sum_r = __uint_as_float(w0.x), *sum_g = __uint_as_float(w0.z), *sum_b = __uint_as_float(w1.x);
+                rng = w1.z;
+                const CameraDev cam = *camp;
+                int x, gy;
+                if (xg_packed) {
+                    const uint32_t xg = *xg_p;
+                    x = (int)(xg & 0xFFFFu), gy = (int)(xg >> 16);
+                } else {
+                    x = (int)(id % (uint32_t)cam.width), gy = tile_global_row(tile, (int)(id / (uint32_t)cam.width));
+                }
+                r = camera_ray(cam, x, gy, rng);
+                depth = 0;
+                trav_begin(T, r.org, ray_dir(r), stack);
+            }
+        } else if (live && T.cur == kTravDone) { // SHADE: the body of shoot_rays after rtcIntersect1 (src/render_wavefront.cpp:245-291)
             f3 res;
             const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab);
             depth++;
             bool ends = done;
-            if (done) {
+            if (SLICED && done) { // the same additions in the same order, on the sums this lane holds in LDS
+                *sum_r = *sum_r + clamp01(res.x), *sum_g = *sum_g + clamp01(res.y), *sum_b = *sum_b + clamp01(res.z);
+            } else if (done) {
                 float4 acc;
                 if (REQ) { // the pixel's previous sample may have been added by another CU: one 16-byte sc1 load, served by the L2
                     const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(accum_rsrc, (int)(id * 16u), 0, 16 /* sc1 */);
@@ -1018,7 +1077,23 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
             } else if (rr_start && depth >= rr_start) {
                 ends = !roulette(rng, r);
             }
-            if (!REQ && ends && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
+            bool handed = false; // SLICED: this sample was the last of its slice
+            if (SLICED && ends && samples_left > 1u) {
+                const SliceNow sn = frame_slices(slices);
+                const unsigned long long cuts = ((unsigned long long)sn.cuts.y << 32) | sn.cuts.x;
+                const uint32_t sh = sn.head.w, s_next = n_samples - (samples_left - 1u); // the sample the pixel goes on with
+                handed = (s_next & ((1u << sh) - 1u)) == 0u && ((cuts >> (s_next >> sh)) & 1ull) != 0ull;
+                if (handed) { // the pixel's state for the lane that takes the next slice: the three sums and the RNG word, tagged with that slice's first sample
+                    const auto rsrc = state_rsrc(sn);
+                    const uint32_t at = id * 32u, tag = sn.head.z + s_next;
+                    u32x4 w0, w1;
+                    w0.x = __float_as_uint(*sum_r), w0.y = tag, w0.z = __float_as_uint(*sum_g), w0.w = tag;
+                    w1.x = __float_as_uint(*sum_b), w1.y = tag, w1.z = rng, w1.w = tag;
+                    __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, (int)at, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
+                }
+            }
+            if (!REQ && ends && !handed && --samples_left) { // the same pixel's next sample: k_wf_generate's body, RNG word still in the register
                 const CameraDev cam = *camp;
                 int x, gy;
                 if (xg_packed) { // (x, global row) as the lane noted them when it took the pixel: no integer division per sample
@@ -1032,6 +1107,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                 ends = false;
             }
             if (ends && cost_out) cost_out[id] = (uint8_t)(depth < 255u ? depth : 255u); // rays of this path: what the cost ordering sorts by
+            if (SLICED && ends && !handed) accum[id] = make_float4(*sum_r, *sum_g, *sum_b, 0.0f); // the pixel's last sample: the accumulator, written once
             if (ends) {
                 live = false, slot_finished = true;
                 if (REQ) requeue = samples_left > 1u;

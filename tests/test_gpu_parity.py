@@ -1331,15 +1331,16 @@ def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypa
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,w,h,spp,depth", [("cornell", {}, 96, 64, 8, 6), ("atrium", {"detail": 1}, 120, 72, 5, 10), ("cube", {}, 97, 61, 3, 4)])
 @pytest.mark.parametrize("slices", [2, 3, 8])
-def test_pixel_slices_keep_the_frame_where_every_slice_has_to_wait(gpu_scenes, oracle, scene_cache, name, kw, w, h, spp, depth, slices):
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_pixel_slices_keep_the_frame_where_every_slice_has_to_wait(gpu_scenes, oracle, scene_cache, cls, kind, name, kw, w, h, spp, depth, slices):
     """A pixel's samples rendered as `slices` slices by different lanes (state through memory) instead of by one lane. On a tile this small
     every lane of the machine is free when the cursor hands out slice j of a pixel, so slice j is taken while slice j - 1 is still being
     rendered: the path where a lane WAITS for its pixel's state runs for every pixel. Same frame, same ray count, bit for bit; more slices
     than samples are cut down to one sample per slice."""
     sd = scene_cache(name, **kw)
     gs = gpu_scenes(name, **kw)
-    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_MEGAKERNEL, depth, spp)
-    r = MegakernelRenderer(gs, (w, h), depth, spp)
+    f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp)
+    r = cls(gs, (w, h), depth, spp)  # (the wavefront renderer's one-launch schedule slices the same way: k_wf_finish<.., SLICED>)
     r.set_schedule(pixel_slices=slices)
     cam = Camera.for_scene(sd, (w, h))
     for frame in range(3):  # the state buffer is never cleared: tags tell the frames apart
@@ -1361,6 +1362,16 @@ def test_pixel_slices_are_chosen_by_tile_size_and_keep_the_frame(gpu_scenes, ora
     gs = gpu_scenes("atrium", detail=1)
     w, h, spp, depth = 1600, 904, 4, 10  # 1.45 M pixels on 393,216 lanes: 3.7 generations
     cam = Camera.for_scene(sd, (w, h))
+    wf = WavefrontRenderer(gs, (w, h), depth, spp)  # the wavefront renderer's default schedule: sliced too, and the frame of its unsliced self
+    wa = wf.render_frame(cam)
+    assert wa.pixel_slices > 1 and wa.kernels["wf_finish"] == 1 and wa.kernels["wf_tile_order"] == 0
+    wf.set_schedule(pixel_slices=0)
+    wp = wf.render_frame(cam)
+    assert wp.pixel_slices == 1 and wp.rays == wa.rays
+    np.testing.assert_array_equal(wa.rgba_f32, wp.rgba_f32)
+    wf.close()
+    _assert_strips_equal_the_oracle(oracle, sd, abi.RT_RENDERER_WAVEFRONT, w, h, depth, spp, [("wavefront, automatic slices", wa.rgba_f32, wa.rgba_u8)], (3, 77),
+                                    what="atrium 1600x904 sliced, wavefront")
     r = MegakernelRenderer(gs, (w, h), depth, spp)
     auto = r.render_frame(cam)
     assert auto.pixel_slices > 1
