@@ -202,8 +202,9 @@ int alloc_tile_buffers_impl(rt_renderer* r) {
     r->tile.local_rows = rows_of_tile(r->tile, r->height);
     r->n_local = (uint32_t)r->tile.local_rows * (uint32_t)r->width;
     const size_t n = std::max<size_t>(r->n_local, 1);
-    const char* ks = std::getenv("RT_KERNEL_STATS");
-    if (ks && ks[0] == '1') HIPCHK(dalloc((void**)&r->d_stats, 24 * sizeof(unsigned long long)));
+    const char* ks = std::getenv("RT_KERNEL_STATS"); // 1: the fully instrumented instantiations; 2: the megakernel's timing-only one (rt_kernels.h)
+    r->stats_level = ks && ks[0] == '2' && r->kind == RT_RENDERER_MEGAKERNEL ? 1 : 2;
+    if (ks && (ks[0] == '1' || ks[0] == '2')) HIPCHK(dalloc((void**)&r->d_stats, 24 * sizeof(unsigned long long)));
     // sized for the LONGEST tile of the split (rank 0's): ncclGather sends the same count from every rank
     TileDev t0 = r->tile;
     t0.rank = 0;
@@ -644,10 +645,12 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
                                                                         (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
         const uint32_t pad = r->mega_lds_pad;
         if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-            (void)hipFuncSetAttribute((const void*)k_megakernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            (void)hipFuncSetAttribute((const void*)k_megakernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
         }
         hipEvent_t e0 = pool_event(r->ev_pool, 0), e1 = pool_event(r->ev_pool, 1);
         if (!e0 || !e1) return fail(RT_ERR_HIP, "hipEventCreate failed");
@@ -672,11 +675,14 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
 #define RT_MEGA_LAUNCH(ST, SL)                                                                                                                    \
     hipLaunchKernelGGL((k_megakernel<ST, SL>), dim3(grid), dim3(kMegaBlock), pad, st, S, r->d_frame, c.width, c.height, r->tile, r->max_depth, r->spp, \
                        r->seed_mode, r->rr_start, d_f32, d_u8, r->d_ray_counter, ST ? r->d_stats : (unsigned long long*)nullptr, sl.n_slices)
-            if (sl.n_slices > 1u) RT_MEGA_LAUNCH(true, true);
-            else RT_MEGA_LAUNCH(true, false);
+            if (r->stats_level == 1) { // timing only
+                if (sl.n_slices > 1u) RT_MEGA_LAUNCH(1, true);
+                else RT_MEGA_LAUNCH(1, false);
+            } else if (sl.n_slices > 1u) RT_MEGA_LAUNCH(2, true);
+            else RT_MEGA_LAUNCH(2, false);
         } else {
-            if (sl.n_slices > 1u) RT_MEGA_LAUNCH(false, true);
-            else RT_MEGA_LAUNCH(false, false);
+            if (sl.n_slices > 1u) RT_MEGA_LAUNCH(0, true);
+            else RT_MEGA_LAUNCH(0, false);
 #undef RT_MEGA_LAUNCH
         }
         HIPCHK(hipGetLastError());
@@ -833,6 +839,9 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
         unsigned long long h[24];
         const unsigned long long rays = local.rays;
         HIPCHK(hipMemcpy(h, r->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        if (r->kind == RT_RENDERER_MEGAKERNEL && r->stats_level == 1)
+            std::fprintf(stderr, "[rt stats] timing-only instantiation: rays %llu | traversal steps %llu | shade/refill rounds %llu\n", rays, h[0], h[4]);
+        else
         std::fprintf(stderr,
                      "[rt stats] rays %llu | inner steps %llu (%.1f lanes/step) | leaf steps %llu (%.1f lanes/step) | "
                      "shade/refill rounds %llu (%.1f lanes/round) | live lanes/step %.1f | per ray: %.2f inner (%.2f in the top 341 nodes), %.2f tri\n",

@@ -124,6 +124,7 @@ struct rt_renderer {
     void* d_slice_state = nullptr;         // pixel slices (rt_kernels.h: SliceDev): 32 bytes per pixel of the tile, zero when allocated, never cleared
     MegaFrame* d_frame = nullptr;          // the frame's constants k_megakernel reads from device memory: camera + slices (copied per frame from h_frame, pinned)
     MegaFrame* h_frame = nullptr;
+    int stats_level = 2;                   // RT_KERNEL_STATS: 2 = the full counters (=1), 1 = the megakernel's timing-only instantiation (=2)
     uint32_t last_slices = 1;              // slices the wavefront renderer's last enqueued frame used (rt_stats.pixel_slices)
     uint32_t slice_tag = 0;                // tag0 of the last frame (grows by kMaxSlices per frame)
     uint32_t rr_start = 0;                 // Russian roulette from this bounce on (0 = off, the reference's behaviour)

@@ -165,7 +165,11 @@ RT_DEV uint32_t frame_slice_bound(const MegaFrame* f, uint32_t j) { // bound[j],
                  : "s"(f), "s"(at));
     return v;
 }
-template <bool STATS, bool SLICED>
+// STATS: 0 the product; 1 TIMING ONLY (RT_KERNEL_STATS=2): cycles in traversal and in shading, shading rounds and traversal steps as four scalar
+// accumulators and two clock reads per round — the instantiation whose cycles per step and per shading round are the product's within a per
+// cent (the full one below holds ~20 more scalars through the loops and spills 32 dwords where the product spills 2: its rounds read 15 %
+// long); 2 FULL (RT_KERNEL_STATS=1): lanes per step kind, node visits in the LDS part of the tree, the frame's timeline as well.
+template <int STATS, bool SLICED>
 __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev S, const MegaFrame* frame, int32_t width, int32_t height, TileDev tile,
                                                     uint32_t max_depth, uint32_t spp, uint32_t seed_mode, uint32_t rr_start, float* __restrict__ out_f32,
                                                     uint8_t* __restrict__ out_u8,
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // RT_ROUND_STAMPS builds: cycles between the stamps of a shading round
     if (STATS) t_begin = t_mark = (long long)__builtin_readcyclecounter();
     unsigned long long wall_begin = 0, wall_exhausted = 0;
-    if (STATS) wall_begin = wall_clock64(); // 100 MHz, the same counter on every CU
+    if (STATS >= 2) wall_begin = wall_clock64(); // 100 MHz, the same counter on every CU
     const uint32_t tiles_x = (uint32_t)(width + 7) >> 3, tiles_y = (uint32_t)(tile.local_rows + 7) >> 3;
     const uint32_t n_slots = tiles_x * tiles_y * 64u; // pixel slots in 8x8-tile order (slots outside the image are skipped)
     const int lane = (int)(threadIdx.x & 63u);
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             const uint32_t p = (uint32_t)lane * n_waves + blockIdx.x * (kMegaBlock / 64u) + (threadIdx.x >> 6);
             if (p < n_slots) take_slot(p, 0u);
             exhausted = true;
-            if (STATS) wall_exhausted = wall_clock64();
+            if (STATS >= 2) wall_exhausted = wall_clock64();
         }
     }
     for (;;) {
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 }
                 if (base + cnt >= total_slots) {
                     exhausted = true;
-                    if (STATS) wall_exhausted = wall_clock64();
+                    if (STATS >= 2) wall_exhausted = wall_clock64();
                 }
             }
         }
@@ -287,24 +291,26 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         for (;;) {
             const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
             if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * kMegaShadePct) break;
-            if (STATS) ws.live_lane_steps += n_live;
+            if (STATS >= 2) ws.live_lane_steps += n_live;
+            if (STATS == 1) ws.inner_steps += (uint32_t)kMegaUnroll; // (timing only: steps of either kind, counted per loop iteration)
             refill.stepped();
-            (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+            (void)trav_step_wave<(STATS >= 2), true>(S, T, stack, top, sg, &ws);
 #pragma unroll
             for (int k = 1; k < kMegaUnroll; ++k) { // the exit tests are checked every kMegaUnroll steps
-                if (STATS) ws.live_lane_steps += n_live;
-                (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
+                if (STATS >= 2) ws.live_lane_steps += n_live;
+                (void)trav_step_wave<(STATS >= 2), true>(S, T, stack, top, sg, &ws);
             }
         }
         if (STATS) {
-            ws.shade_rounds++, ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
+            ws.shade_rounds++;
+            if (STATS >= 2) ws.shade_lanes += (uint32_t)__popcll(__ballot(live && T.cur == kTravDone));
             const long long now = (long long)__builtin_readcyclecounter();
             t_trav += now - t_mark, t_mark = now;
         }
         // SHADE the lanes whose traversal is complete
         __builtin_amdgcn_s_setprio(RT_ROUND_PRIO);
 #ifdef RT_ROUND_STAMPS
-        if (STATS) ck[7] = (long long)__builtin_readcyclecounter();
+        if (STATS >= 2) ck[7] = (long long)__builtin_readcyclecounter();
 #endif
         bool pixel_finished = false;
         {
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 }
             } else {
                 f3 res;
-                const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS ? ck : nullptr);
+                const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS >= 2 ? ck : nullptr);
 #ifdef RT_TAIL_PRIO
                 __builtin_amdgcn_s_setprio(RT_TAIL_PRIO);
 #endif
@@ -373,7 +379,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 r = camera_ray(frame_camera(frame, width, height), x, gy, rng);
             }
             if (live && depth < kPend) trav_begin(T, r.org, ray_dir(r), stack);
-            RT_STAMP_AFTER((STATS ? ck : nullptr), 5, T.ox); // sky lanes, half conversions, path ends, camera rays, trav_begin
+            RT_STAMP_AFTER((STATS >= 2 ? ck : nullptr), 5, T.ox); // sky lanes, half conversions, path ends, camera rays, trav_begin
         }
         refill.round(pixel_finished);
         if (STATS) t_shade += (long long)__builtin_readcyclecounter() - t_mark;
@@ -390,9 +396,11 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         atomicAdd(stats_out + 8, dur), atomicMax(stats_out + 9, dur), atomicAdd(stats_out + 10, 1ull);
         atomicAdd(stats_out + 11, (unsigned long long)t_trav), atomicAdd(stats_out + 12, (unsigned long long)t_shade);
         // frame timeline on the chip-wide 100 MHz clock: first wave start, first wave that found the pixel queue empty, last wave end
-        atomicMin(stats_out + 13, wall_begin);
-        if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
-        atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
+        if (STATS >= 2) {
+            atomicMin(stats_out + 13, wall_begin);
+            if (wall_exhausted) atomicMin(stats_out + 14, wall_exhausted);
+            atomicMax(stats_out + 15, (unsigned long long)wall_clock64());
+        }
 #ifdef RT_ROUND_STAMPS
         for (int i = 1; i <= 5; ++i) atomicAdd(stats_out + 15 + i, (unsigned long long)ck[i]);
 #endif

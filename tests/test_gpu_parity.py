@@ -1325,6 +1325,15 @@ def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypa
         _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"stats {cls.__name__} {sched}")
         r.close()
     assert "[rt stats]" in capfd.readouterr().err
+    monkeypatch.setenv("RT_KERNEL_STATS", "2")  # the megakernel's timing-only instantiation (cycles per step / per shading round close to the product's)
+    f, b, rays = _oracle_frame(oracle, sd, w, h, abi.RT_RENDERER_MEGAKERNEL, depth, spp)
+    for slices in (0, 3):
+        r = MegakernelRenderer(gs, (w, h), depth, spp)
+        r.set_schedule(pixel_slices=slices)
+        got = r.render_frame(cam)
+        _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"timing-only megakernel, slices {slices}")
+        r.close()
+    assert "timing-only instantiation" in capfd.readouterr().err
 
 
 # ---- pixel slices of the megakernel (rt_schedule::pixel_slices) ------------------------------------------------------------
