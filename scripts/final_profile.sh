@@ -18,7 +18,7 @@ bench)
   timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 --dump-pmc $out/pmc_bench.json > $out/bench.json 2> $out/bench.err
   echo bench done ;;
 ktrace)
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-pipelined > $out/bench_under_rocprof.json 2> $out/kt.err
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-pipelined --no-sensitivity > $out/bench_under_rocprof.json 2> $out/kt.err
   echo ktrace done ;;
 tables)
   python3 scripts/schedule_probe.py 64 > $out/schedules_64spp.txt 2>&1
@@ -29,8 +29,8 @@ tilepmc)
   bash scripts/tile_pmc.sh final mega "8 1" > $out/tile_pmc.txt 2>&1
   echo tilepmc done ;;
 stats)
-  RT_KERNEL_STATS=1 python3 scripts/tile_scaling.py 64 mega 1,8 2>&1 | grep -E "rt stats|Renderer" | tail -8 > $out/stats.log
-  RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
+  (echo "== RT_KERNEL_STATS=2: the timing-only instantiation (cycles per step / per shading round: the product's within ~1 %)"; RT_KERNEL_STATS=2 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -6; echo "== RT_KERNEL_STATS=1: the fully instrumented instantiation (lanes per step, node visits, frame timeline; its cycles read ~5-30 % long)"; RT_KERNEL_STATS=1 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -8) > $out/stats.log
+  RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc --no-sensitivity 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
   echo stats done ;;
 misc)
   python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 mega > $out/pixel_slices.txt 2>&1

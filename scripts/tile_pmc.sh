@@ -6,7 +6,7 @@ set -e
 TAG=${1:-tile}; R=${2:-mega}; WORLDS=${3:-"8 1"}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8
-O=gpurun_out/r04/pmc_$TAG
+O=gpurun_out/r05/pmc_$TAG
 mkdir -p $O
 for WORLD in $WORLDS; do
   i=0
@@ -17,7 +17,7 @@ for WORLD in $WORLDS; do
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_GATE_EN1_sum"; do
     i=$((i+1))
-    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/w${WORLD}_p$i -- python3 scripts/tile_scaling.py 64 $R $WORLD > $O/w${WORLD}_p$i.out 2> $O/w${WORLD}_p$i.err || { echo "pass $i (1/$WORLD) failed"; tail -3 $O/w${WORLD}_p$i.err; }
+    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/w${WORLD}_p$i -- python3 scripts/tile_scaling.py 64 $R $WORLD 1 > $O/w${WORLD}_p$i.out 2> $O/w${WORLD}_p$i.err || { echo "pass $i (1/$WORLD) failed"; tail -3 $O/w${WORLD}_p$i.err; }
   done
 done
 python3 - $O $WORLDS <<'PY' | tee $O/summary.txt
