@@ -858,6 +858,11 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     chunk_slots &= 0xFFFFu;
     // the static first chunk. Guided: static_pct of the queue in equal parts, whole generations of 64 slots, at least one
     uint32_t first_slots = chunk_slots;
+    // SLICED: NO static chunk — every slot comes from the cursor. A later slice of a pixel waits for the slice before it, and that is only safe if the
+    // earlier slot has been taken by a wave that RUNS: a slot a wave owns by its index alone belongs to a wave that may not be resident yet (a
+    // second frame in flight, any other kernel on the device), while resident waves wait for it and hold the wave slots it needs (seen: 7.8 s per
+    // frame with two sliced frames in flight)
+    if (SLICED) first_slots = 0;
     if (tail_guided) {
         const uint32_t per_wave = (uint32_t)(((unsigned long long)n * static_pct / 100u) / (n_waves ? n_waves : 1u));
         first_slots = per_wave < 64u ? 64u : (per_wave & ~63u);
@@ -1035,7 +1040,11 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         __builtin_amdgcn_s_setprio(0);
         bool requeue = false, slot_finished = false, hand_on = false;
         // a queue entry's first ray is the queue's length, already in the host's sum (unless the queue has holes): every other ray counts here
-        wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
+        {
+            const unsigned long long traced = __ballot(live && T.cur == kTravDone && !(SLICED && depth >= kPend));
+            wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
+            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(8); // only lanes that wait for a state: do not spin at full speed
+        }
         if (SLICED && live && T.cur == kTravDone && depth >= kPend) { // a lane that waits for its pixel's state: four {value, tag} granules, taken when all carry this slice's tag
             const SliceNow sn = frame_slices(slices);
             const auto rsrc = state_rsrc(sn);
