@@ -21,9 +21,9 @@ ktrace)
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-pipelined --no-sensitivity > $out/bench_under_rocprof.json 2> $out/kt.err
   echo ktrace done ;;
 tables)
-  python3 scripts/schedule_probe.py 64 > $out/schedules_64spp.txt 2>&1
-  python3 scripts/config_table.py > $out/config_table.txt 2>&1
-  python3 scripts/tile_scaling.py 64 "" 1,2,4,8 1,2 > $out/tile_scaling.txt 2>&1
+  timeout -k 10 400 python3 scripts/schedule_probe.py 64 > $out/schedules_64spp.txt 2>&1
+  timeout -k 10 400 python3 scripts/config_table.py > $out/config_table.txt 2>&1
+  timeout -k 10 400 python3 scripts/tile_scaling.py 64 "" 1,2,4,8 1,2 > $out/tile_scaling.txt 2>&1
   echo tables done ;;
 tilepmc)
   bash scripts/tile_pmc.sh final mega "8 1" > $out/tile_pmc.txt 2>&1
@@ -33,9 +33,9 @@ stats)
   RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc --no-sensitivity 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
   echo stats done ;;
 misc)
-  python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 mega > $out/pixel_slices.txt 2>&1
-  python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 wave >> $out/pixel_slices.txt 2>&1
-  python3 scripts/tile_floor.py 64 8,16,32,64 > $out/tile_floor.txt 2>&1
-  python3 scripts/shoot_rate.py > $out/shoot_rate.txt 2>&1
+  timeout -k 10 400 python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 mega > $out/pixel_slices.txt 2>&1
+  timeout -k 10 400 python3 scripts/slice_probe.py 1,2,4,8 0,-1 64 wave >> $out/pixel_slices.txt 2>&1
+  timeout -k 10 400 python3 scripts/tile_floor.py 64 8,16,32,64 > $out/tile_floor.txt 2>&1
+  timeout -k 10 400 python3 scripts/shoot_rate.py > $out/shoot_rate.txt 2>&1
   echo misc done ;;
 esac; done
