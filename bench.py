@@ -64,15 +64,23 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 EXTEND_BYTES_PER_RAY = 40
 SHADE_BYTES_PER_RAY = 92
 SHOOT_BYTES_PER_RAY = 76
-# The wavefront renderer's default schedule: one queue per frame, written by k_wf_generate (34 B state + 4 B RNG r/w)
-# and consumed by k_wf_finish, which follows every path to its end in registers:
-#   k_wf_finish per PATH: reads ray state 34 B + RNG 4 B, writes RNG 4 B, reads + writes the accumulator 32 B       = 74 B/path
-FINISH_BYTES_PER_PATH = 74
+# The wavefront renderer's default schedule: one queue per frame, written by k_wf_generate and consumed by k_wf_finish, which
+# keeps a pixel in its lane for all its samples (every camera ray but the first is made in the kernel) and follows every path to its end in
+# registers. Its algorithmic stream, per PIXEL: the queue entry 34 B + the RNG word read and written back 8 B = 42 B; per PATH: the accumulator
+# read and written, 32 B (src/render_wavefront.cpp:340-354 does the same read-modify-write in K5).
+FINISH_BYTES_PER_PIXEL = 42
+FINISH_ACCUM_BYTES_PER_PATH = 32
 # the megakernel's HBM stream is its output — one fp32 RGBA store (16 B) and, as the reference's K1 writes it too
 # (src/render_megakernel.cpp:154-158), one RGBA8 store (4 B) per pixel and frame — plus, since round 5, the pixel state that changes lanes
 # between two slices of a pixel's samples (rt_kernels.h: SliceDev): 32 B written + 32 B read per hand-over.
 MEGAKERNEL_BYTES_PER_PIXEL = 20
 SLICE_HANDOVER_BYTES = 64
+# k_wf_finish<.., SLICED> (the one-launch schedule on tiles with more pixels than lanes, round 5) keeps a pixel's sums in LDS within a slice:
+# nothing per path; per PIXEL the 42 B above + the accumulator written once (16 B) + 64 B per hand-over
+FINISH_SLICED_ACCUM_BYTES_PER_PIXEL = 16
+# kernel names as rocprofv3 prints them, up to the template arguments that tell the instantiations apart (STATS, REQ, LIMIT; the fourth,
+# SLICED, follows the frame's geometry): matched as substrings of the profiler's kernel names
+FINISH_KERNEL, SHOOT_KERNEL = "k_wf_finish<false, false, false", "k_wf_finish<false, false, true"
 # SURVEY §8d "traversal bytes/ray" of this build: 64-B BVH4 nodes, 40-B triangle records, 124 B of hit shading; per-ray counts of the
 # atrium from the kernel's own counters (RT_KERNEL_STATS=1; re-measured in every run by the workload_sensitivity leg): 17.28 node visits,
 # 9.28 of them in the LDS-staged top of the tree, 2.36 triangle tests
@@ -103,6 +111,7 @@ def parse_args(argv=None):
                     help="frames enqueued at once, each in its own renderer and strip buffer (1 = the reference's one frame at a "
                          "time; 2 hides the end-of-frame drain of the per-pixel sample chains behind the next frame)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-frames-in-flight measurement")
+    ap.add_argument("--pipelined-renderer", default="", help="the renderer of the two-frames-in-flight leg (default: the headline's)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU-oracle sample")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes after the timed region")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the information-only workload_sensitivity leg (the megakernel on the rotated atrium and the voxel terrain)")
@@ -356,7 +365,7 @@ def main() -> int:
             box = [lead]
             dist.broadcast_object_list(box, src=0)
             lead = box[0]
-        pipelined = measure(lead, 2) if F0 == 1 and not args.no_pipelined else None
+        pipelined = measure(args.pipelined_renderer or lead, 2) if F0 == 1 and not args.no_pipelined else None
 
     setup_all = [setup]
     if use_dist:
@@ -381,16 +390,17 @@ def main() -> int:
         }
         if pipelined:
             out["two_frames_in_flight"] = {"renderer": pipelined["renderer"], "value": pipelined["value"], "unit": "Mrays/s",
-                                           "ms_per_step": pipelined["ms_per_step"],
+                                           "ms_per_step": pipelined["ms_per_step"], "device_ms_per_step": pipelined["device_ms_per_step"],
                                            "note": "same K frames with the next frame enqueued (second renderer + strip buffer) before the "
                                                    "current one is collected; not the headline: ms_per_step is then no longer one frame's latency"}
         if world == 1 and not rehearsal and not args.no_sensitivity and "megakernel" in out["renderers"]:
             try:
                 out["workload_sensitivity"] = workload_sensitivity(args, out["renderers"]["megakernel"]["value"], abi, Scene, Camera, MegakernelRenderer)
                 mine = out["workload_sensitivity"]["scenes"].get("atrium", {})
-                if "node_visits_per_ray" in mine:  # this run's counters instead of the constants
-                    mk = out["renderers"]["megakernel"]
-                    mk["roofline"]["traversal"] = traversal_object({k: mine[k] for k in ATRIUM_VISITS}, mk["value"] * 1e6, "measured in this run (RT_KERNEL_STATS=1 child, 4 spp)")
+                if "node_visits_per_ray" in mine:  # this run's counters instead of the constants (the tree and the rays are the same for both renderers)
+                    for mk in (out["renderers"].get(n) for n in ("megakernel", "wavefront")):
+                        if mk:
+                            mk["roofline"]["traversal"] = traversal_object({k: mine[k] for k in ATRIUM_VISITS}, mk["value"] * 1e6, "measured in this run (RT_KERNEL_STATS=1 child, 4 spp, megakernel)")
             except Exception as e:  # information only: never the reason a bench line is missing
                 out["workload_sensitivity"] = {"error": str(e)[:300]}
         if world == 1 and not rehearsal:
@@ -434,7 +444,7 @@ def shared_scene(args, rank, world, use_dist):
 def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
     """The roofline object of one renderer on THIS rank, as SURVEY §8(d) states it: algorithmic bytes per unit of work x units per second
     over the WHOLE timed region (wall clock: every launch, tail and gap included) against the HBM peak —
-        wavefront renderers: rays/s x bytes per ray (76 B fused per-bounce kernel; 40 + 92 B EXTEND + SHADE; 74 B per PATH for the one-launch schedule)
+        wavefront renderers: rays/s x bytes per ray (76 B fused per-bounce kernel; 40 + 92 B EXTEND + SHADE; one-launch schedule: per PATH 32 B of accumulator + 42 B per pixel / spp, or, sliced, (58 B + 64 B per hand-over) per pixel / spp)
         megakernel         : pixels/s x (20 B + 64 B per slice hand-over)
     `per_launch` keeps the dominant kernel's own figure (its bytes / its mean launch duration from hipEvents on the launch's stream: what
     `rocprofv3 --kernel-trace --stats` reports for that kernel); where stream lanes overlap, launch durations overlap too, which is why that
@@ -443,13 +453,16 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
     rays = tot.get("profiled_rays", tot["rays"])  # rays of the frames the kernel durations were taken over
     pixels = rows * W
     if name == "wavefront":
-        kernel, unit, units_per_s, bytes_per_unit = "k_wf_finish<false, false, false>", "path", pixels * args.spp * args.steps / elapsed, FINISH_BYTES_PER_PATH
-        bytes_per_launch = FINISH_BYTES_PER_PATH * (pixels * args.spp * args.steps) / max(hot_launches, 1)
+        slices = max(int(tot.get("pixel_slices", 1)), 1)
+        per_path = round(FINISH_ACCUM_BYTES_PER_PATH + FINISH_BYTES_PER_PIXEL / args.spp if slices == 1 else
+                         (FINISH_BYTES_PER_PIXEL + FINISH_SLICED_ACCUM_BYTES_PER_PIXEL + SLICE_HANDOVER_BYTES * (slices - 1)) / args.spp, 3)
+        kernel, unit, units_per_s, bytes_per_unit = FINISH_KERNEL, "path", pixels * args.spp * args.steps / elapsed, per_path
+        bytes_per_launch = per_path * (pixels * args.spp * args.steps) / max(hot_launches, 1)
     elif name == "wavefront_per_bounce":
         kernel, unit, units_per_s, bytes_per_unit = "k_wf_extend", "ray", rays_all / elapsed, EXTEND_BYTES_PER_RAY + SHADE_BYTES_PER_RAY
         bytes_per_launch = EXTEND_BYTES_PER_RAY * rays / max(hot_launches, 1)
     elif name == "wavefront_per_bounce_fused":
-        kernel, unit, units_per_s, bytes_per_unit = "k_wf_finish<false, false, true>", "ray", rays_all / elapsed, SHOOT_BYTES_PER_RAY
+        kernel, unit, units_per_s, bytes_per_unit = SHOOT_KERNEL, "ray", rays_all / elapsed, SHOOT_BYTES_PER_RAY
         bytes_per_launch = SHOOT_BYTES_PER_RAY * rays / max(hot_launches, 1)
     else:
         slices = max(int(tot.get("pixel_slices", 1)), 1)
@@ -488,7 +501,7 @@ def roofline_of(name, args, tot, rows, W, rays_all, elapsed, kernel_frames):
                             "ballot + mbcnt ranks, slots from a per-workgroup block (one device atomic per 256 rays)")
     elif name == "wavefront":
         roof["schedule"] = "one k_wf_generate + one k_wf_finish launch per frame (rt_schedule default: DESIGN.md §5)"
-    else:
+    if name in ("wavefront", "megakernel"):
         roof["pixel_slices"] = max(int(tot.get("pixel_slices", 1)), 1)
         roof["traversal"] = traversal_object(ATRIUM_VISITS, rays_all / elapsed, "constants of bench.py (profiles/r04_wave_stats.txt); replaced by this run's counters when the workload_sensitivity leg ran")
     roof["note"] = ("a traversal kernel's algorithmic HBM traffic is its ray-state / frame stream only (SURVEY.md §8d): the fraction is tiny by construction. Its work is "
@@ -623,8 +636,8 @@ PMC_PASSES = (("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_MISS_sum"),
               ("SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_TRANS_F32"),
               ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_SALU"),
               ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"))
-KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": ("k_wf_finish<false, false, false>",), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade"),
-              "wavefront_per_bounce_fused": ("k_wf_finish<false, false, true>",)}
+KERNELS_OF = {"megakernel": ("k_megakernel",), "wavefront": (FINISH_KERNEL,), "wavefront_per_bounce": ("k_wf_extend", "k_wf_shade"),
+              "wavefront_per_bounce_fused": (SHOOT_KERNEL,)}
 
 
 def live_pmc(args, renderers):
@@ -702,7 +715,8 @@ def attach_pmc(out, args):
     """roofline.traffic (HBM-side bytes per launch of the dominant kernel) and roofline.binding (the bound that binds) of the headline
     renderer and of the per-bounce pipeline, from counters collected in this run."""
     lead = out["config"]["renderer"]
-    want = [lead] + [n for n in ("wavefront_per_bounce", "wavefront_per_bounce_fused") if n != lead and n in out["renderers"]]
+    # both one-launch renderers (they are within a few per cent of each other: which one leads differs from box to box) and the per-bounce pipelines
+    want = [lead] + [n for n in ("megakernel", "wavefront", "wavefront_per_bounce", "wavefront_per_bounce_fused") if n != lead and n in out["renderers"]]
     c, source = None, None
     if not args.no_live_pmc:
         try:

@@ -645,11 +645,20 @@ RT_DEV void shade_tables_fill(const SceneDev& S, u32x4* nm, u32x4* mat) { // coo
 #define RT_STAMP_AFTER(ck, i, VAL) do { } while (0)
 #endif
 // USE_TAB = false: kernels that stage no tables (the dense SHADE kernel, the probes)
-template <bool USE_TAB = false>
+// `sink(colour)`: what the caller does with an ended path's contribution, called WHERE it is made (the miss branch, the absorbed branch). Returned
+// through a reference it was live across the join of those branches — the point of a shading round where most is live — and the kernels that
+// keep a ray per lane held it in scratch memory: three stores per path end and three reloads, each waited for on its own.
+// (NoSink: the colour is returned in `result`. The instantiations are told apart by type, not by an `if`: hipcc's register allocation at the 80-register
+// limit is sensitive to every extra value — the unsliced megakernel spills 2 dwords with `result`, 13 with a sink that stores into it.)
+struct NoSink {};
+template <class Sink> struct is_no_sink { static constexpr bool value = false; };
+template <> struct is_no_sink<NoSink> { static constexpr bool value = true; };
+template <bool USE_TAB = false, class Sink = NoSink>
 RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, const Hit& h, f3& org, f3& dir, f3& att, f3& rad, f3& result,
-                      long long* ck = nullptr) {
+                      long long* ck = nullptr, const Sink& sink = Sink{}) {
     if (h.tri == kNoTri) {
-        result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+        if constexpr (is_no_sink<Sink>::value) result = att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad);
+        else sink(att * (mk3(S.sky[0], S.sky[1], S.sky[2]) + rad));
         return true;
     }
     const float4* sp = reinterpret_cast<const float4*>(S.shade + h.tri);
@@ -745,7 +754,8 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
         att = att * satt;
         return false;
     }
-    result = att * rad;
+    if constexpr (is_no_sink<Sink>::value) result = att * rad;
+    else sink(att * rad);
     return true;
 }
 

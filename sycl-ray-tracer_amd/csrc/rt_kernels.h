@@ -41,14 +41,15 @@ RT_DEV f3 ray_dir(const RayState& r) { return mk3(h2f(r.dir[0]), h2f(r.dir[1]), 
 // and T.d are r.org and h2f(r.dir) exactly, trav_begin put them there — so that r.org / r.dir are written here and consumed by the
 // trav_begin (or the queue store) that follows, live only inside the round: six lane registers less through the traversal loop.
 // (with `tab`: the kernel's staged shading tables; without: the memory path only)
-template <bool FROM_TRAV = false>
+// `sink`: see shade_hit
+template <bool FROM_TRAV = false, class Sink = NoSink>
 RT_DEV bool shade_bounce(const SceneDev& S, uint32_t& rng, RayState& r, const Hit& h, f3& result, const Trav* T = nullptr, const ShadeTables* tab = nullptr,
-                         long long* ck = nullptr) {
+                         long long* ck = nullptr, const Sink& sink = Sink{}) {
     f3 org = FROM_TRAV ? T->o : r.org;
     f3 dir = FROM_TRAV ? T->d : ray_dir(r);
     f3 att = mk3(h2f(r.att[0]), h2f(r.att[1]), h2f(r.att[2]));
     f3 rad = mk3(h2f(r.rad[0]), h2f(r.rad[1]), h2f(r.rad[2]));
-    const bool done = FROM_TRAV ? shade_hit<true>(S, *tab, rng, h, org, dir, att, rad, result, ck) : shade_hit<false>(S, ShadeTables{}, rng, h, org, dir, att, rad, result);
+    const bool done = FROM_TRAV ? shade_hit<true>(S, *tab, rng, h, org, dir, att, rad, result, ck, sink) : shade_hit<false>(S, ShadeTables{}, rng, h, org, dir, att, rad, result, nullptr, sink);
     r.org = org;
     r.dir[0] = f2h(dir.x), r.dir[1] = f2h(dir.y), r.dir[2] = f2h(dir.z);
     r.att[0] = f2h(att.x), r.att[1] = f2h(att.y), r.att[2] = f2h(att.z);
@@ -332,8 +333,18 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                     start = true;
                 }
             } else {
+                // An ended path's colour (paths that outlive max_depth add nothing). SLICED: added where it is made, in shade_hit's two ending branches — carried
+                // to their join it was kept in scratch memory (three stores per path end, three reloads each waited for on its own). The unsliced
+                // instantiation has the registers for it, and spills MORE (2 -> 12 dwords) with the additions inside the branches.
                 f3 res;
-                const bool done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS >= 2 ? ck : nullptr);
+                const auto add = [color_r, color_g, color_b](const f3& c) { *color_r = *color_r + c.x, *color_g = *color_g + c.y, *color_b = *color_b + c.z; };
+                bool done;
+                if (SLICED) {
+                    done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS >= 2 ? ck : nullptr, add);
+                } else {
+                    done = shade_bounce<true>(S, rng, r, T.best, res, &T, &tab, STATS >= 2 ? ck : nullptr);
+                    if (done) add(res);
+                }
 #ifdef RT_TAIL_PRIO
                 __builtin_amdgcn_s_setprio(RT_TAIL_PRIO);
 #endif
@@ -341,7 +352,6 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 bool killed = false;
                 if (rr_start && !done && depth >= rr_start && depth < max_depth) killed = !roulette(rng, r);
                 if (done || killed || depth == max_depth) {
-                    if (done) *color_r = *color_r + res.x, *color_g = *color_g + res.y, *color_b = *color_b + res.z; // paths that outlive max_depth add (0,0,0)
                     s++;
                     bool handed = false; // this sample was the last of its slice: the pixel goes on in another lane
                     SliceNow sn{};

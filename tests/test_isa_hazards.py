@@ -92,9 +92,10 @@ def _check(lines):
 def test_nothing_touches_the_node_words_between_their_asm_loads_and_their_waits(listing):
     groups = _check(listing)
     # every traversal kernel instantiation carries the fetch (three inner steps per loop iteration in the persistent kernels)
-    want = ["k_megakernelILb0ELb0", "k_megakernelILb0ELb1", "k_megakernelILb1ELb0", "k_megakernelILb1ELb1", "k_wf_extendILb0", "k_wf_extendILb1",
-            "k_wf_finishILb0ELb0ELb0", "k_wf_finishILb0ELb0ELb1", "k_wf_finishILb0ELb1ELb0", "k_wf_finishILb1ELb0ELb0", "k_wf_finishILb1ELb0ELb1",
-            "k_wf_finishILb1ELb1ELb0", "k_intersect_batch"]
+    want = ["k_megakernelILi0ELb0", "k_megakernelILi0ELb1", "k_megakernelILi1ELb0", "k_megakernelILi1ELb1", "k_megakernelILi2ELb0", "k_megakernelILi2ELb1",
+            "k_wf_extendILb0", "k_wf_extendILb1",
+            "k_wf_finishILb0ELb0ELb0ELb0", "k_wf_finishILb0ELb0ELb0ELb1", "k_wf_finishILb0ELb0ELb1ELb0", "k_wf_finishILb0ELb1ELb0ELb0",
+            "k_wf_finishILb1ELb0ELb0ELb0", "k_wf_finishILb1ELb0ELb0ELb1", "k_wf_finishILb1ELb0ELb1ELb0", "k_wf_finishILb1ELb1ELb0ELb0", "k_intersect_batch"]
     for w in want:
         assert any(w in k for k in groups), f"no asm node fetch found in {w}: {sorted(groups)}"
 
