@@ -317,7 +317,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && depth < kPend); // every lane of the round but those that wait for a state has traced a ray
             wave_rays += (unsigned long long)__popcll(traced);
-            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(8); // only lanes that wait for a state (small tiles): do not spin at full speed
+            // only lanes that wait for a state: look again in ~3 us, not at once — a look is two 16-byte loads per lane past every cache, and at a frame's end thousands of
+            // waves may be in this state at the same time while the few lanes they wait for need the memory system (a hand-over a few us late costs nothing: slices take ms)
+            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(127);
         }
         if (live && T.cur == kTravDone) {
             bool start = false; // this lane starts a path: a camera ray (src/render_megakernel.cpp:148-151)
@@ -1053,7 +1055,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && !(SLICED && depth >= kPend));
             wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
-            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(8); // only lanes that wait for a state: do not spin at full speed
+            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(127); // only lanes that wait for a state: look again in ~3 us (see k_megakernel)
         }
         if (SLICED && live && T.cur == kTravDone && depth >= kPend) { // a lane that waits for its pixel's state: four {value, tag} granules, taken when all carry this slice's tag
             const SliceNow sn = frame_slices(slices);
