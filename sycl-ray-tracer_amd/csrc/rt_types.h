@@ -1,5 +1,5 @@
 // rt_types.h — data layouts of the device-resident scene and of the kernel parameter block.
-// Shared by the host builder (scene_build.cpp) and the HIP kernels (rt_kernels.hip).
+// Shared by the host builder (scene_build.cpp) and the HIP kernels (rt_kernels.h, rt_device.h).
 #pragma once
 #include <cstdint>
 
