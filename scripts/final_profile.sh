@@ -29,7 +29,7 @@ tilepmc)
   bash scripts/tile_pmc.sh final mega "8 1" > $out/tile_pmc.txt 2>&1
   echo tilepmc done ;;
 stats)
-  (echo "== RT_KERNEL_STATS=2: the timing-only instantiation (cycles per step / per shading round: the product's within ~1 %)"; RT_KERNEL_STATS=2 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -6; echo "== RT_KERNEL_STATS=1: the fully instrumented instantiation (lanes per step, node visits, frame timeline; its cycles read ~5-30 % long)"; RT_KERNEL_STATS=1 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -8) > $out/stats.log
+  (echo "== RT_KERNEL_STATS=2: the timing-only instantiation (cycles per step / per shading round: the product's within ~1 %)"; RT_KERNEL_STATS=2 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -12; echo "== RT_KERNEL_STATS=1: the fully instrumented instantiation (lanes per step, node visits, frame timeline; its cycles read ~5-30 % long)"; RT_KERNEL_STATS=1 python3 scripts/tile_scaling.py 64 mega 1,8 1 2>&1 | grep -E "rt stats|Renderer" | tail -16) > $out/stats.log
   RT_KERNEL_STATS=1 python3 bench.py --steps 2 --warmup 1 --renderer megakernel --no-cpu-baseline --no-live-pmc --no-sensitivity 2>&1 | grep -E "frame timeline" | tail -6 >> $out/stats.log
   echo stats done ;;
 misc)

@@ -305,7 +305,8 @@ int alloc_tile_buffers(rt_renderer* r) {
 //   forced    : rt_schedule::pixel_slices >= 2 slices of that geometry whatever G is (tests, sweeps)
 SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint32_t tag0) { // grid: workgroups of kMegaBlock threads the launch keeps resident
     SliceDev sl{};
-    sl.state = r->d_slice_state, sl.n_slices = 1, sl.tag0 = tag0;
+    sl.state = r->d_slice_state, sl.n_slices = 1, sl.tag0 = tag0, sl.wait_cap = kSliceWaitCap;
+    if (const char* e = dev_knob("RT_SLICE_WAIT_CAP")) sl.wait_cap = (uint32_t)std::strtoul(e, nullptr, 10); // tests: give up after that many looks
     for (uint32_t k = 0; k < kMaxSlices; ++k) sl.bound[k] = r->spp;
     const int32_t want = r->sched.pixel_slices;
     const double G = (double)n_slots / ((double)grid * kMegaBlock);
@@ -353,6 +354,9 @@ SliceDev mega_slices(const rt_renderer* r, uint32_t grid, uint32_t n_slots, uint
             sl.bound[sl.n_slices - 1] = v, sl.cuts |= 1ull << v, sl.n_slices++, prev = v;
         }
     }
+    // test hook (developer build): the cursor hands out the later slices, but no lane ever ends one — every lane that takes a later slice waits for a
+    // state that is never written, which is exactly the logic error the kernels' bounded wait has to turn into an error code
+    if (dev_knob("RT_INJECT_SLICE_LOSS") && sl.n_slices > 1) sl.cuts = 0;
     return sl;
 }
 
@@ -806,6 +810,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
             unsigned long long ctr[8] = {0};
             HIPCHK(hipMemcpy(ctr, r->d_ray_counter, sizeof(ctr), hipMemcpyDeviceToHost));
             local.rays = ctr[0];
+            if (ctr[2]) return fail(RT_ERR_HIP, "k_megakernel: a pixel slice waited for its pixel's state for longer than any hand-over takes (internal error)");
         } else {
             uint64_t rays = 0;
             const uint32_t D = r->max_depth;
@@ -813,7 +818,7 @@ int frame_end(rt_renderer* r, rt_stats* stats) {
                 if (!L.n_local) continue;
                 HIPCHK(hipMemcpy(L.h_counts.data(), L.d_counts, L.h_counts.size() * 4, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(L.h_extra.data(), L.d_extra, L.h_extra.size() * 8, hipMemcpyDeviceToHost));
-                if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: a queue hand-over stalled or overflowed (internal error word " + std::to_string((unsigned long long)L.h_extra[r->spp]) + ": 1 / 2 dynamic queue, 3 SHOOT's slot allocator)");
+                if (L.h_extra[r->spp]) return fail(RT_ERR_HIP, "k_wf_finish: a queue hand-over stalled or overflowed (internal error word " + std::to_string((unsigned long long)L.h_extra[r->spp]) + ": 1 / 2 dynamic queue, 3 SHOOT's slot allocator, 4 pixel-slice hand-over)");
                 const bool shoot_frame = r->sched.fused_bounce && std::min(D, r->sched.finish_depth) > 0; // SHOOT queues have holes: counted on the device
                 for (uint32_t s = 0; s < r->spp; ++s) {
                     if (!shoot_frame)

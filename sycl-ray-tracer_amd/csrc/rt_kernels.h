@@ -126,7 +126,8 @@ struct RefillPolicy { // wave-uniform, ONE scalar register (k_megakernel is at t
     }
 };
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, tag0) == 8 && offsetof(SliceDev, cuts) == 16 && offsetof(SliceDev, bound) == 24, "frame_* below read MegaFrame by byte offset");
+static_assert(offsetof(MegaFrame, sl) == 56 && offsetof(SliceDev, tag0) == 8 && offsetof(SliceDev, cuts) == 16 && offsetof(SliceDev, bound) == 24 && offsetof(SliceDev, wait_cap) == 60,
+              "frame_* below read MegaFrame by byte offset");
 RT_DEV CameraDev frame_camera(const MegaFrame* f, int32_t width, int32_t height) { // the twelve floats as three scalar loads, here and now
     u32x4 a, b, c;
     asm volatile("s_load_dwordx4 %0, %3, 0x0\n\t"
@@ -166,6 +167,28 @@ RT_DEV uint32_t frame_slice_bound(const MegaFrame* f, uint32_t j) { // bound[j],
                  : "s"(f), "s"(at));
     return v;
 }
+RT_DEV uint32_t frame_slice_wait_cap(const MegaFrame* f) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x74\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(v)
+                 : "s"(f));
+    return v;
+}
+// A wave of a SLICED launch that holds nothing but lanes waiting for their pixel's state (no ray traced in this round, no lane traversing): sleep ~3 us before
+// the next look — a look is two 16-byte loads per lane past every cache, and at a frame's end thousands of waves may be in this state while the
+// few lanes they wait for need the memory system (a hand-over a few us late costs nothing: slices take ms) — and count the looks in the wave's LDS word
+// (no register through the traversal loop). After `wait_cap` looks in the wave's life — seconds of waiting: a logic error — the wave's waiting lanes take
+// WHATEVER the state buffer holds (slice_wait_over) and run to their ends, so the wave leaves by its ordinary way out (an exit of its own from the
+// wave's loop cost the sliced megakernel 90 more spilled registers); the caller leaves an error word when this returns true.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_word;
+RT_DEV bool slice_wait_count(lds_u32_word* looks, const MegaFrame* f) {
+    __builtin_amdgcn_s_sleep(127);
+    const uint32_t n = *looks + 1u; // (every lane reads and writes the wave's word with the same value)
+    *looks = n;
+    return n == frame_slice_wait_cap(f) + 1u;
+}
+RT_DEV bool slice_wait_over(const lds_u32_word* looks, const MegaFrame* f) { return *looks > frame_slice_wait_cap(f); }
 // STATS: 0 the product; 1 TIMING ONLY (RT_KERNEL_STATS=2): cycles in traversal and in shading, shading rounds and traversal steps as four scalar
 // accumulators and two clock reads per round — the instantiation whose cycles per step and per shading round are the product's within a per
 // cent (the full one below holds ~20 more scalars through the loops and spills 32 dwords where the product spills 2: its rounds read 15 %
@@ -199,6 +222,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     lds_f32* const color_b = color_g + kMegaBlock;
     RayState r{};
     Trav T;
+    __shared__ uint32_t pend_looks[SLICED ? kMegaBlock / 64u : 1u]; // per wave: rounds in which it held nothing but waiting lanes (slice_wait_exceeded)
+    lds_u32_word* const looks = (lds_u32_word*)pend_looks + (SLICED ? threadIdx.x >> 6 : 0u);
+    if (SLICED) *looks = 0u;
     RT_SHADE_LDS
     RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
@@ -317,9 +343,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && depth < kPend); // every lane of the round but those that wait for a state has traced a ray
             wave_rays += (unsigned long long)__popcll(traced);
-            // only lanes that wait for a state: look again in ~3 us, not at once — a look is two 16-byte loads per lane past every cache, and at a frame's end thousands of
-            // waves may be in this state at the same time while the few lanes they wait for need the memory system (a hand-over a few us late costs nothing: slices take ms)
-            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(127);
+            if (SLICED && traced == 0ull && __ballot(live && T.cur != kTravDone) == 0ull && slice_wait_count(looks, frame) && lane == 0)
+                atomicMax(ray_counter + 2, 1ull); // the host: RT_ERR_HIP
         }
         if (live && T.cur == kTravDone) {
             bool start = false; // this lane starts a path: a camera ray (src/render_megakernel.cpp:148-151)
@@ -329,7 +354,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 const uint32_t at = pix * 32u, tag = sn.head.z + s;
                 const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
                 const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
-                if (w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) {
+                if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(looks, frame)) {
                     *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.z), *color_b = __uint_as_float(w1.x);
                     rng = w1.z;
                     start = true;
@@ -843,6 +868,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + (SLICED ? 0u : threadIdx.x);
     const bool xg_packed = !SLICED && camp->width < 65536 && camp->height < 65536;
+    __shared__ uint32_t pend_looks[SLICED ? kMegaBlock / 64u : 1u]; // per wave: rounds in which it held nothing but waiting lanes (slice_wait_exceeded)
+    lds_u32_word* const looks = (lds_u32_word*)pend_looks + (SLICED ? threadIdx.x >> 6 : 0u);
+    if (SLICED) *looks = 0u;
     __shared__ float sum_lds[SLICED ? 3u * kMegaBlock : 1u]; // SLICED: the pixel's three sums while this lane holds it
     typedef __attribute__((address_space(3))) float lds_f32_t;
     lds_f32_t* const sum_r = (lds_f32_t*)sum_lds + (SLICED ? threadIdx.x : 0u);
@@ -1055,7 +1083,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && !(SLICED && depth >= kPend));
             wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
-            if (SLICED && traced == 0ull) __builtin_amdgcn_s_sleep(127); // only lanes that wait for a state: look again in ~3 us (see k_megakernel)
+            if (SLICED && traced == 0ull && __ballot(live && T.cur != kTravDone) == 0ull && slice_wait_count(looks, slices) && lane == 0 && fq.error)
+                __hip_atomic_store(fq.error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the host: RT_ERR_HIP
         }
         if (SLICED && live && T.cur == kTravDone && depth >= kPend) { // a lane that waits for its pixel's state: four {value, tag} granules, taken when all carry this slice's tag
             const SliceNow sn = frame_slices(slices);
@@ -1063,7 +1092,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
             const uint32_t at = id * 32u, tag = sn.head.z + (n_samples - samples_left);
             const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
             const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
-            if (w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) {
+            if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(looks, slices)) {
                 *sum_r = __uint_as_float(w0.x), *sum_g = __uint_as_float(w0.z), *sum_b = __uint_as_float(w1.x);
                 rng = w1.z;
                 const CameraDev cam = *camp;

@@ -46,6 +46,8 @@ constexpr uint32_t kMegaWaves = 6;     // waves per SIMD the kernels are compile
 //           cursor after slice j - 1 was; the host sizes the slices so that a sweep takes longer than the slice before it
 //           (mega_slices). A lane whose slice is not ready yet (never seen at full size; small tiles) looks again in its wave's next
 //           shading round. No lane ever waits for a LATER slot: nothing can deadlock.
+//   bound : all the same, a wave that holds ONLY waiting lanes counts its looks (one every ~3 us) and gives up after `wait_cap` of them — seconds —
+//           with an error word the host turns into RT_ERR_HIP: a logic error must become an error code, not a wave that never leaves.
 //   cuts  : a lane knows its slice by the sample it starts with (taken from bound[] when the slot is claimed) and finds the slice's end
 //           in a 64-bit mask: bit k set = a slice ends before sample k << shift (shift = 0 up to 64 spp).
 constexpr uint32_t kMaxSlices = 8;
@@ -56,8 +58,9 @@ struct SliceDev {
     unsigned long long cuts;
     uint32_t bound[kMaxSlices]; // slice j renders samples bound[j - 1] (0 for j = 0) ... bound[j] - 1; bound[n_slices - 1 ...] = spp
     uint32_t n_slices;          // 1: a lane keeps its pixel for all its samples
-    uint32_t pad;
+    uint32_t wait_cap;          // looks of a wave with nothing but waiting lanes before it gives up (above)
 };
+constexpr uint32_t kSliceWaitCap = 1u << 22; // x ~3.4 us of sleep + the look itself: > 15 s
 // The frame's constants that only a shading round or a refill reads — the camera's twelve floats, the slices — live in DEVICE memory and are
 // loaded where they are used (scalar loads, hot in the scalar cache): as kernel arguments hipcc kept them in ~35 scalar registers through the
 // traversal loop, in a kernel that has none to spare (with the slices on top: 38 scalar registers spilled into vector lanes, 46 vector
