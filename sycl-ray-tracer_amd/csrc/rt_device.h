@@ -672,7 +672,6 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
     bool lds = false;
     if (USE_TAB) lds = __builtin_amdgcn_ballot_w64(!((iw & kPackedInstMask) < tab.n_nm && (iw >> kPackedInstBits) < tab.n_mat)) == 0ull;
     MatRec mat;
-    const InstRec* inst = nullptr;
     if (USE_TAB && __builtin_expect(lds, 1)) {
         const uint32_t at = (iw >> kPackedInstBits) * 2u;
         const u32x4 a = tab.mat[at], b = tab.mat[at + 1u];
@@ -683,7 +682,7 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
     } else {
         // The material record is read WHOLE, here, as three 16-byte words: one memory round trip after the shading record's, then one for
         // the texel. Read field by field at their uses (round 2) they became five more dependent fetches, each stuck behind a branch.
-        inst = S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw);
+        const InstRec* inst = S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw);
         const u32x4* mp = reinterpret_cast<const u32x4*>(S.mats + (S.packed_mat ? (iw >> kPackedInstBits) : inst->material));
         const u32x4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
         mat.type = m0.x, mat.tex_kind = m0.y, mat.color[0] = __uint_as_float(m0.z), mat.color[1] = __uint_as_float(m0.w);
@@ -725,6 +724,7 @@ RT_DEV bool shade_hit(const SceneDev& S, const ShadeTables& tab, uint32_t& rng, 
     } else {
         // (loads and their wait in ONE asm statement: hipcc's wait-count pass would otherwise merge this branch's pending loads into the
         // join below and make the LDS path wait for the TEXEL there — vmcnt counts in order — before it may touch the same registers)
+        const InstRec* inst = S.inst + (S.packed_mat ? (iw & kPackedInstMask) : iw); // (computed again, here: as a pointer kept from the material fetch on it was 64 bits of scratch memory in the LDS path)
         u32x4 a, b;
         uint32_t c;
         asm volatile("global_load_dwordx4 %0, %3, off\n\t"

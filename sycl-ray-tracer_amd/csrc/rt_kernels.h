@@ -189,6 +189,15 @@ RT_DEV bool slice_wait_count(lds_u32_word* looks, const MegaFrame* f) {
     return n == frame_slice_wait_cap(f) + 1u;
 }
 RT_DEV bool slice_wait_over(const lds_u32_word* looks, const MegaFrame* f) { return *looks > frame_slice_wait_cap(f); }
+// The wave's word sits behind the three planes of per-lane colour sums, and its address is worked out from the lane's own slot in the first plane WHERE it
+// is needed (the asm keeps hipcc from hoisting it out of the wave's loop): as a pointer of its own it was one more vector register through the traversal
+// loop, and the pixel's column went to scratch memory for it — a scratch round trip at every path end.
+RT_DEV lds_u32_word* slice_looks_word(const void __attribute__((address_space(3))) * lane_slot, const void __attribute__((address_space(3))) * planes) {
+    uint32_t a = (uint32_t)(size_t)lane_slot;
+    asm volatile("" : "+v"(a));
+    const uint32_t base = (uint32_t)(size_t)planes;
+    return (lds_u32_word*)(size_t)(base + 3u * kMegaBlock * 4u + (((a - base) >> 6) & ~3u));
+}
 // STATS: 0 the product; 1 TIMING ONLY (RT_KERNEL_STATS=2): cycles in traversal and in shading, shading rounds and traversal steps as four scalar
 // accumulators and two clock reads per round — the instantiation whose cycles per step and per shading round are the product's within a per
 // cent (the full one below holds ~20 more scalars through the loops and spills 32 dwords where the product spills 2: its rounds read 15 %
@@ -215,23 +224,21 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
     unsigned long long wave_rays = 0; // rays traced by this wave (wave-uniform: a scalar pair, no lane register, no reduction at the end)
     // the pixel's colour sum lives in LDS (three planes, one slot per lane): touched once per PATH, it would otherwise hold three of the 80
     // vector registers through every traversal step of a kernel that spills
-    __shared__ float color_lds[3 * kMegaBlock];
+    __shared__ float color_lds[3 * kMegaBlock + (SLICED ? kMegaBlock / 64 : 0)]; // (+ SLICED: a word per wave, slice_looks_word)
     typedef __attribute__((address_space(3))) float lds_f32;
     lds_f32* const color_r = (lds_f32*)color_lds + threadIdx.x;
     lds_f32* const color_g = color_r + kMegaBlock;
     lds_f32* const color_b = color_g + kMegaBlock;
     RayState r{};
     Trav T;
-    __shared__ uint32_t pend_looks[SLICED ? kMegaBlock / 64u : 1u]; // per wave: rounds in which it held nothing but waiting lanes (slice_wait_exceeded)
-    lds_u32_word* const looks = (lds_u32_word*)pend_looks + (SLICED ? threadIdx.x >> 6 : 0u);
-    if (SLICED) *looks = 0u;
+    if (SLICED) *slice_looks_word(color_r, (lds_f32*)color_lds) = 0u; // per wave: rounds in which it held nothing but waiting lanes (slice_wait_count)
     RT_SHADE_LDS
     RT_TRAVERSAL_LDS(kMegaBlock)
     T.cur = kTravDone;
     // A lane is `live` when it owns a pixel slice with samples left; `depth` then holds the bounces of its current path so far — or, in a
     // SLICED launch, kPend: the lane has taken a later slice of a pixel (`s` = the sample it starts with) and waits for the state the slice before ends with. It LOOKS for that
-    // state in every shading round of its wave, where a ray is started anyway (a waiting lane counts as one that waits for shading, so rounds
-    // keep coming). A state poll of its own beside the refill, with its own copy of the camera-ray code and its own way round the wave's
+    // state in every shading round of its wave, where a ray is started anyway (the rounds the wave's other lanes bring about; a wave with nothing
+    // but waiting lanes goes from round to round, ~3 us apart). A state poll of its own beside the refill, with its own copy of the camera-ray code and its own way round the wave's
     // loop, cost more registers than the kernel has: 51 spilled, 122 -> 145 ms.
     constexpr uint32_t kPend = 0x40000000u;
     bool live = false;
@@ -312,12 +319,19 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             if (exhausted) break;
             continue;
         }
-        // TRAVERSE until kMegaShadePct of the live lanes are waiting for shading
+        // TRAVERSE until kMegaShadePct of the lanes that have a ray are waiting for shading. Lanes that wait for their pixel's STATE (SLICED) are not
+        // among them: counted as waiting they ended the traversal phase before its first step whenever they were three quarters of a wave, and the wave's
+        // traversing lanes — which lanes of other waves may be waiting for in turn — stood still until enough states had arrived from elsewhere (seen as
+        // frames of seconds with two sliced frames in flight; with a lost hand-over injected, as a wave that never ends). They look for their state
+        // in the rounds the other lanes bring about, and a wave that holds nothing else looks every ~3 us (below).
         if (STATS) t_mark = (long long)__builtin_readcyclecounter();
         const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
+        // (in the loop's test the lanes that wait for a state count as waiting, as every lane with T.cur == kTravDone does: the threshold is raised by their number instead)
+        const uint32_t n_rays = SLICED ? (uint32_t)__popcll(__ballot(live && depth < kPend)) : n_live;
+        const uint32_t shade_at = n_rays * kMegaShadePct + (n_live - n_rays) * 100u;
         for (;;) {
-            const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting
-            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= n_live * kMegaShadePct) break;
+            const bool waiting = live && T.cur == kTravDone; // every live lane is traversing or waiting (for shading, or for its pixel's state)
+            if ((uint32_t)__popcll(__ballot(waiting)) * 100u >= shade_at) break;
             if (STATS >= 2) ws.live_lane_steps += n_live;
             if (STATS == 1) ws.inner_steps += (uint32_t)kMegaUnroll; // (timing only: steps of either kind, counted per loop iteration)
             refill.stepped();
@@ -343,8 +357,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && depth < kPend); // every lane of the round but those that wait for a state has traced a ray
             wave_rays += (unsigned long long)__popcll(traced);
-            if (SLICED && traced == 0ull && __ballot(live && T.cur != kTravDone) == 0ull && slice_wait_count(looks, frame) && lane == 0)
-                atomicMax(ray_counter + 2, 1ull); // the host: RT_ERR_HIP
+            if (SLICED && traced == 0ull && __ballot(live && depth < kPend) == 0ull && slice_wait_count(slice_looks_word(color_r, (lds_f32*)color_lds), frame) && lane == 0) atomicMax(ray_counter + 2, 1ull); // (the host: RT_ERR_HIP)
         }
         if (live && T.cur == kTravDone) {
             bool start = false; // this lane starts a path: a camera ray (src/render_megakernel.cpp:148-151)
@@ -354,7 +367,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
                 const uint32_t at = pix * 32u, tag = sn.head.z + s;
                 const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
                 const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
-                if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(looks, frame)) {
+                if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(slice_looks_word(color_r, (lds_f32*)color_lds), frame)) {
                     *color_r = __uint_as_float(w0.x), *color_g = __uint_as_float(w0.z), *color_b = __uint_as_float(w1.x);
                     rng = w1.z;
                     start = true;
@@ -413,7 +426,9 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_megakernel(SceneDev 
             }
             if (start) {
                 depth = 0;
-                r = camera_ray(frame_camera(frame, width, height), x, gy, rng);
+                int cx = x, cy = gy;
+                asm volatile("" : "+v"(cx), "+v"(cy)); // (or hipcc converts the pixel's coordinates to float where the lane takes the pixel and keeps them in scratch memory until here)
+                r = camera_ray(frame_camera(frame, width, height), cx, cy, rng);
             }
             if (live && depth < kPend) trav_begin(T, r.org, ray_dir(r), stack);
             RT_STAMP_AFTER((STATS >= 2 ? ck : nullptr), 5, T.ox); // sky lanes, half conversions, path ends, camera rays, trav_begin
@@ -868,14 +883,12 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + (SLICED ? 0u : threadIdx.x);
     const bool xg_packed = !SLICED && camp->width < 65536 && camp->height < 65536;
-    __shared__ uint32_t pend_looks[SLICED ? kMegaBlock / 64u : 1u]; // per wave: rounds in which it held nothing but waiting lanes (slice_wait_exceeded)
-    lds_u32_word* const looks = (lds_u32_word*)pend_looks + (SLICED ? threadIdx.x >> 6 : 0u);
-    if (SLICED) *looks = 0u;
-    __shared__ float sum_lds[SLICED ? 3u * kMegaBlock : 1u]; // SLICED: the pixel's three sums while this lane holds it
+    __shared__ float sum_lds[SLICED ? 3u * kMegaBlock + kMegaBlock / 64u : 1u]; // SLICED: the pixel's three sums while this lane holds it (+ a word per wave: slice_looks_word)
     typedef __attribute__((address_space(3))) float lds_f32_t;
     lds_f32_t* const sum_r = (lds_f32_t*)sum_lds + (SLICED ? threadIdx.x : 0u);
     lds_f32_t* const sum_g = sum_r + (SLICED ? kMegaBlock : 0u);
     lds_f32_t* const sum_b = sum_g + (SLICED ? kMegaBlock : 0u);
+    if (SLICED) *slice_looks_word(sum_r, (lds_f32_t*)sum_lds) = 0u; // rounds in which the wave held nothing but waiting lanes (slice_wait_count)
     bool chunk_dq = false; // REQ: the wave's current chunk is a range of POSITIONS of the dynamic queue
     bool drained = false;  // REQ: the dynamic queue has no position left (wave-uniform)
     // REQ: this lane holds a position of the dynamic queue and polls it. A waiting lane has no pixel, so its position lives in `id` and
@@ -1067,9 +1080,11 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         }
         idle_polls = 0;
         const TravSigns sg = trav_signs(T); // every ray of this traversal phase has been started by now
-        for (;;) { // TRAVERSE until kMegaShadePct of the live lanes wait for shading
+        const uint32_t n_rays = SLICED ? (uint32_t)__popcll(__ballot(live && depth < kPend)) : n_live; // lanes that wait for a state are not among them (k_megakernel)
+        const uint32_t shade_at = n_rays * kMegaShadePct + (n_live - n_rays) * 100u;
+        for (;;) { // TRAVERSE until kMegaShadePct of the lanes that have a ray wait for shading
             const bool done_trav = live && T.cur == kTravDone;
-            if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= n_live * kMegaShadePct) break;
+            if ((uint32_t)__popcll(__ballot(done_trav)) * 100u >= shade_at) break;
             if (STATS) ws.live_lane_steps += n_live * kMegaUnroll;
             refill.stepped();
             (void)trav_step_wave<STATS, true>(S, T, stack, top, sg, &ws);
@@ -1083,8 +1098,8 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
         {
             const unsigned long long traced = __ballot(live && T.cur == kTravDone && !(SLICED && depth >= kPend));
             wave_rays += (unsigned long long)__popcll(__ballot(live && T.cur == kTravDone && !(first_counted && depth == first_depth) && !(SLICED && depth >= kPend)));
-            if (SLICED && traced == 0ull && __ballot(live && T.cur != kTravDone) == 0ull && slice_wait_count(looks, slices) && lane == 0 && fq.error)
-                __hip_atomic_store(fq.error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the host: RT_ERR_HIP
+            if (SLICED && traced == 0ull && __ballot(live && depth < kPend) == 0ull && slice_wait_count(slice_looks_word(sum_r, (lds_f32_t*)sum_lds), slices) && lane == 0 && fq.error)
+                __hip_atomic_store(fq.error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the host: RT_ERR_HIP)
         }
         if (SLICED && live && T.cur == kTravDone && depth >= kPend) { // a lane that waits for its pixel's state: four {value, tag} granules, taken when all carry this slice's tag
             const SliceNow sn = frame_slices(slices);
@@ -1092,7 +1107,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
             const uint32_t at = id * 32u, tag = sn.head.z + (n_samples - samples_left);
             const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)at, 0, 16 /* sc1 */);
             const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at + 16u), 0, 16 /* sc1 */);
-            if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(looks, slices)) {
+            if ((w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag) || slice_wait_over(slice_looks_word(sum_r, (lds_f32_t*)sum_lds), slices)) {
                 *sum_r = __uint_as_float(w0.x), *sum_g = __uint_as_float(w0.z), *sum_b = __uint_as_float(w1.x);
                 rng = w1.z;
                 const CameraDev cam = *camp;

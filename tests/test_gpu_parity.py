@@ -11,6 +11,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -1360,6 +1361,36 @@ def test_pixel_slices_keep_the_frame_where_every_slice_has_to_wait(gpu_scenes, o
     got = r.render_frame(cam)
     assert got.pixel_slices == 1
     _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{name} unsliced")
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,kind", KINDS)
+def test_a_lost_slice_hand_over_becomes_an_error_code_not_a_hung_gpu(dev_scenes, oracle, monkeypatch, cls, kind):
+    """Every wait of a sliced kernel is for a slot a running or finished wave holds, so no wave can wait for ever — by design. The kernels bound
+    the wait all the same: a wave that holds nothing but waiting lanes counts its looks and, after `wait_cap` of them (the product: > 15 s),
+    lets its lanes run on with whatever the state buffer holds and leaves an error word: the frame call returns RT_ERR_HIP. Injected here
+    (developer build): the cursor hands out second slices, but the cut mask is empty, so no lane ever ends a first slice and no state is ever
+    written; the cap is lowered to a few thousand looks. The renderer renders the right frame again afterwards."""
+    gs = dev_scenes("cornell")
+    sd = gs.desc
+    w, h, depth, spp = 96, 64, 6, 6
+    cam = Camera.for_scene(sd, (w, h))
+    f, b, rays = _oracle_frame(oracle, sd, w, h, kind, depth, spp)
+    r = cls(gs, (w, h), depth, spp)
+    r.set_schedule(pixel_slices=2)
+    monkeypatch.setenv("RT_INJECT_SLICE_LOSS", "1")
+    monkeypatch.setenv("RT_SLICE_WAIT_CAP", "3000")
+    t0 = time.perf_counter()
+    with pytest.raises(abi.RtError) as e:
+        r.render_frame(cam)
+    assert e.value.status == abi.RT_ERR_HIP and "slice" in str(e.value), e.value
+    assert time.perf_counter() - t0 < 30.0
+    monkeypatch.delenv("RT_INJECT_SLICE_LOSS")
+    monkeypatch.delenv("RT_SLICE_WAIT_CAP")
+    got = r.render_frame(cam)
+    assert got.pixel_slices == 2
+    _assert_frames_equal(got.rgba_f32, got.rgba_u8, got.rays, f, b, rays, f"{cls.__name__} after a lost hand-over")
     r.close()
 
 
