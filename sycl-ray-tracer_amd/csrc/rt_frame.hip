@@ -645,8 +645,10 @@ int enqueue_frame(rt_renderer* r, const rt_camera* cam, float* d_f32, uint8_t* d
         // persistent waves: enough to fill every SIMD at the kernel's occupancy, never more than there are tiles
         constexpr uint32_t mega_wpb = kMegaBlock / 64;
         // (in the chain regime — fewer tiles than wave slots — 64 pixels on 4,050 waves beat 42 pixels on all 6,144: 29.5 against 33.7 ms)
-        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
-                                                                        (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
+        uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((tiles_x * tiles_y + mega_wpb - 1u) / mega_wpb,
+                                                                  (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
+        if (const char* e = dev_knob("RT_MEGA_CHAIN_GRID_PCT")) // experiment: more (emptier) waves than the tile needs, in per cent of what it needs
+            grid = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)((unsigned long long)grid * std::strtoul(e, nullptr, 10) / 100u), (uint32_t)r->n_cus * 4u * r->mega_occ / mega_wpb));
         const uint32_t pad = r->mega_lds_pad;
         if (pad) { // static + dynamic LDS may exceed the 64 KiB a launch gets without asking
             (void)hipFuncSetAttribute((const void*)k_megakernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
