@@ -93,7 +93,10 @@ RT_DEV unsigned long long wave_sum_u64(uint32_t v) {
 #define RT_ROUND_PRIO 0
 #endif
 constexpr int kMegaUnroll = 3;         // traversal steps between two checks of the loop's exit condition (1 -> 3: +1.2 %)
-constexpr uint32_t kMegaShadePct = 75; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
+#ifndef RT_MEGA_SHADE_PCT
+#define RT_MEGA_SHADE_PCT 75
+#endif
+constexpr uint32_t kMegaShadePct = RT_MEGA_SHADE_PCT; // shade when this share of the live lanes is waiting (70 / 75 / 80 / 85: 7318-7350 / 7349-7362 / 7309-7341 / 7263-7266 Mrays/s)
 constexpr uint32_t kMegaRefill = 1;    // idle lanes that trigger a pixel fetch — as the STARTING value of RefillPolicy:
 // A refill is an atomic round trip plus the camera-ray code, issued for the whole wave however few lanes take
 // part, and a lane that waits for company is idle: with lanes falling idle at a rate L per unit of wave time, refilling at T idle lanes
