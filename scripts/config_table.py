@@ -1,5 +1,5 @@
 """BASELINE.json configs[1..4] on one GPU (4K frame of config[4]: this GPU's 1/8 tile): Mrays/s and ms/frame of both renderers.
-   config_table.py sweep [ITERATIONS=6] [OUTDIR=gpurun_out/r04/sweep]: the reference's published sweep instead (benchmark.py:6-47: depth 10..50 at
+   config_table.py sweep [ITERATIONS=6] [OUTDIR=gpurun_out/r05/sweep]: the reference's published sweep instead (benchmark.py:6-47: depth 10..50 at
    128 spp and 32..512 spp at depth 10, both renderers, 1920x1080; 6 runs per point, the first discarded) through the C++ `raytracer` CLI on the
    generated atrium and, for its minecraft.glb row, the voxel terrain; scraped with the reference's regular expressions (benchmark.py:49-55),
    CSV in the reference's column order, d = 10 -> 50 ratio beside the reference's (benchmark_avg.csv:2-11)."""
@@ -53,7 +53,7 @@ def sweep(iters, out):
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "sweep":
-    sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 6, (Path(sys.argv[3]) if len(sys.argv) > 3 else REPO / "gpurun_out" / "r04" / "sweep").resolve())
+    sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 6, (Path(sys.argv[3]) if len(sys.argv) > 3 else REPO / "gpurun_out" / "r05" / "sweep").resolve())
     sys.exit(0)
 from rtamd.renderer import Scene, Camera, MegakernelRenderer, WavefrontRenderer
 CASES = [("cube 512x512 16spp d10", scenes.cube_scene, {}, 512, 512, 16, 10, 1),
