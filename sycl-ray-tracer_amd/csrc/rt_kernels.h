@@ -884,7 +884,13 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
     // packed, in one LDS word per lane (images of up to 65,535 x 65,535; larger ones divide as before).
     __shared__ uint32_t xg_lds[SLICED ? 1u : kMegaBlock];
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-    lds_u32_t* const xg_p = (lds_u32_t*)xg_lds + (SLICED ? 0u : threadIdx.x);
+    // (the lane's word, its address worked out from the lane's stack slot where it is needed: as a pointer of its own it was kept in scratch memory,
+    // and every camera ray began with a scratch round trip)
+    auto xg_word = [&]() {
+        uint32_t a = stack.base;
+        asm volatile("" : "+v"(a));
+        return (lds_u32_t*)(size_t)(a - (uint32_t)(size_t)(lds_i32*)lds_stack + (uint32_t)(size_t)(lds_u32_t*)xg_lds);
+    };
     const bool xg_packed = !SLICED && camp->width < 65536 && camp->height < 65536;
     __shared__ float sum_lds[SLICED ? 3u * kMegaBlock + kMegaBlock / 64u : 1u]; // SLICED: the pixel's three sums while this lane holds it (+ a word per wave: slice_looks_word)
     typedef __attribute__((address_space(3))) float lds_f32_t;
@@ -1047,7 +1053,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                                 if (SLICED) *sum_r = 0.0f, *sum_g = 0.0f, *sum_b = 0.0f; // (k_wf_init left the accumulator at zero)
                                 if (!REQ && n_samples > 1u && xg_packed) { // the pixel's coordinates for its later camera rays: two divisions ONCE per pixel
                                     const uint32_t w = (uint32_t)camp->width;
-                                    *xg_p = (id % w) | ((uint32_t)tile_global_row(tile, (int)(id / w)) << 16);
+                                    *xg_word() = (id % w) | ((uint32_t)tile_global_row(tile, (int)(id / w)) << 16);
                                 }
                                 trav_begin(T, r.org, ray_dir(r), stack);
                                 live = true;
@@ -1116,7 +1122,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                 const CameraDev cam = *camp;
                 int x, gy;
                 if (xg_packed) {
-                    const uint32_t xg = *xg_p;
+                    const uint32_t xg = *xg_word();
                     x = (int)(xg & 0xFFFFu), gy = (int)(xg >> 16);
                 } else {
                     x = (int)(id % (uint32_t)cam.width), gy = tile_global_row(tile, (int)(id / (uint32_t)cam.width));
@@ -1173,7 +1179,7 @@ __global__ void __launch_bounds__(kMegaBlock, kMegaWaves) k_wf_finish(SceneDev S
                 const CameraDev cam = *camp;
                 int x, gy;
                 if (xg_packed) { // (x, global row) as the lane noted them when it took the pixel: no integer division per sample
-                    const uint32_t xg = *xg_p;
+                    const uint32_t xg = *xg_word();
                     x = (int)(xg & 0xFFFFu), gy = (int)(xg >> 16);
                 } else {
                     x = (int)(id % (uint32_t)cam.width), gy = tile_global_row(tile, (int)(id / (uint32_t)cam.width));
