@@ -1339,7 +1339,8 @@ def test_instrumented_kernels_render_the_same_frame(gpu_scenes, oracle, monkeypa
 
 # ---- pixel slices of the megakernel (rt_schedule::pixel_slices) ------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,kw,w,h,spp,depth", [("cornell", {}, 96, 64, 8, 6), ("atrium", {"detail": 1}, 120, 72, 5, 10), ("cube", {}, 97, 61, 3, 4)])
+@pytest.mark.parametrize("name,kw,w,h,spp,depth", [("cornell", {}, 96, 64, 8, 6), ("atrium", {"detail": 1}, 120, 72, 5, 10), ("cube", {}, 97, 61, 3, 4),
+                                                   ("cornell", {}, 48, 40, 67, 4)])  # (67 samples: slices end at multiples of TWO samples, the last unit is a short one)
 @pytest.mark.parametrize("slices", [2, 3, 8])
 @pytest.mark.parametrize("cls,kind", KINDS)
 def test_pixel_slices_keep_the_frame_where_every_slice_has_to_wait(gpu_scenes, oracle, scene_cache, cls, kind, name, kw, w, h, spp, depth, slices):
