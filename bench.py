@@ -365,7 +365,14 @@ def main() -> int:
             box = [lead]
             dist.broadcast_object_list(box, src=0)
             lead = box[0]
-        pipelined = measure(args.pipelined_renderer or lead, 2) if F0 == 1 and not args.no_pipelined else None
+        pipelined = None
+        if F0 == 1 and not args.no_pipelined:
+            try:  # information only: never the reason a bench line is missing (with several ranks a failure here would have to be collective: let it raise)
+                pipelined = measure(args.pipelined_renderer or lead, 2)
+            except Exception as e:
+                if use_dist:
+                    raise
+                pipelined = {"renderer": args.pipelined_renderer or lead, "value": None, "ms_per_step": None, "device_ms_per_step": None, "error": str(e)[:300]}
 
     setup_all = [setup]
     if use_dist:
@@ -393,6 +400,8 @@ def main() -> int:
                                            "ms_per_step": pipelined["ms_per_step"], "device_ms_per_step": pipelined["device_ms_per_step"],
                                            "note": "same K frames with the next frame enqueued (second renderer + strip buffer) before the "
                                                    "current one is collected; not the headline: ms_per_step is then no longer one frame's latency"}
+            if pipelined.get("error"):
+                out["two_frames_in_flight"]["error"] = pipelined["error"]
         if world == 1 and not rehearsal and not args.no_sensitivity and "megakernel" in out["renderers"]:
             try:
                 out["workload_sensitivity"] = workload_sensitivity(args, out["renderers"]["megakernel"]["value"], abi, Scene, Camera, MegakernelRenderer)
