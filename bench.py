@@ -96,8 +96,8 @@ RENDERERS = ("wavefront", "megakernel", "wavefront_per_bounce", "wavefront_per_b
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--renderer", choices=["auto", *RENDERERS], default=os.environ.get("RT_BENCH_RENDERER", "auto"),
                     help="auto = measure all renderers of the path, headline the fastest")
     ap.add_argument("--width", type=int, default=1920)
